@@ -1,0 +1,299 @@
+/*
+ * svi_hot.h — C ABI of the MI355X-native hot path of svi_mapper.
+ *
+ * Two things live behind this boundary:
+ *
+ *   1. the BRIEF-256 Hamming matcher that the reference reaches through
+ *      std::shared_ptr<cv::DescriptorMatcher>  (src/core/CTriangulator.cpp:12,
+ *      shared with CFundamentalMatcher at src/core/CFundamentalMatcher.cpp:20), and
+ *   2. the Levenberg-Marquardt bundle adjustment that the reference reaches through
+ *      g2o::SparseOptimizer + BlockSolverX + LinearSolverCholmod
+ *      (src/optimization/Cg2oOptimizer.cpp:83-89).
+ *
+ * Conventions
+ *   - every entry point returns an svi_status (0 == SVI_OK); no exception crosses the boundary;
+ *     the reference's "no match" exceptions (src/exceptions/CExceptionNoMatchFound.h) become
+ *     idx == -1 in the output arrays, never an error code.
+ *   - plain pointers and sizes only. "host" pointers are caller-owned host memory; entry points
+ *     with the _dev suffix take device (HBM) pointers, enqueue on the handle's HIP stream and do
+ *     NOT synchronise (call svi_*_sync).
+ *   - handles are opaque, not thread-safe; distinct handles may be used from distinct threads.
+ *   - the library never falls back to a CPU implementation: without a gfx950 device every
+ *     compute entry point returns SVI_ERR_NO_DEVICE.
+ */
+#ifndef SVI_HOT_H
+#define SVI_HOT_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SVI_HOT_VERSION 100 /* 0.1.0 */
+
+typedef enum svi_status {
+    SVI_OK              = 0,
+    SVI_ERR_INVALID     = 1, /* bad argument (null pointer, negative size, unknown id ...) */
+    SVI_ERR_NO_DEVICE   = 2, /* no HIP device / not a gfx950 */
+    SVI_ERR_HIP         = 3, /* a HIP runtime call failed; see svi_last_error() */
+    SVI_ERR_STATE       = 4, /* call out of order (e.g. optimize before initialize) */
+    SVI_ERR_UNSUPPORTED = 5, /* graph shape outside what the path supports */
+    SVI_ERR_NOT_FOUND   = 6, /* vertex id not in graph */
+    SVI_ERR_IO          = 7, /* .g2o file could not be read / written */
+    SVI_ERR_COMM        = 8  /* the all-reduce hook reported failure */
+} svi_status;
+
+const char* svi_status_string(int status);
+/* Message of the last failure on the calling thread ("" if none). */
+const char* svi_last_error(void);
+int         svi_version(void);
+/* Number of visible HIP devices; 0 if none (never fails). */
+int         svi_device_count(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Matcher  — replaces cv::BFMatcher(NORM_HAMMING)::match (k = 1) and cv::norm(a,b,NORM_HAMMING)
+ * as used at CTriangulator.cpp:93,156,227,298 and CFundamentalMatcher.cpp:540,657,1080,1200,
+ * 1584,1708,2356 (match) / :404,:423,:453,:473,:573,:691,:2375 (norm), plus the rectified
+ * triangulation CTriangulator::getPointInLEFT (CTriangulator.cpp:326-356).
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct svi_matcher svi_matcher;
+
+/* Epipolar gate of the batched form. Pair (i,j) is a candidate iff
+ *     |t_uv[j].v - q_uv[i].v| <= v_tol   &&   q_umin[i] <= t_uv[j].u < q_umax[i]
+ * The reference enumerates integer pixels of ONE row in ascending u
+ * (CTriangulator.cpp:67-77, 201-211, 272-282): v_tol = 0, q_umax = u_L. */
+typedef struct svi_gate {
+    const float* q_uv;   /* nq x 2 (u,v) */
+    const float* t_uv;   /* nt x 2 (u,v) */
+    const float* q_umin; /* nq */
+    const float* q_umax; /* nq */
+    float        v_tol;
+} svi_gate;
+
+/* stream == NULL: the handle creates and owns a HIP stream; otherwise it borrows the caller's
+ * hipStream_t (so the caller can bracket launches with its own events). */
+int svi_matcher_create(int device, void* stream, svi_matcher** out);
+int svi_matcher_destroy(svi_matcher* m);
+int svi_matcher_sync(svi_matcher* m);
+/* the hipStream_t the handle launches on */
+void* svi_matcher_stream(svi_matcher* m);
+
+/* k=1 brute force Hamming NN over 256-bit descriptors (32 B rows, contiguous).
+ *   out_idx[i]  = smallest j attaining min_j popcount(q_i ^ t_j) over gated j,
+ *                 or -1 if there is no candidate or min >= max_dist_exclusive
+ *                 (reference cut-offs: 100 CTriangulator.cpp:13,107; 50 CFundamentalMatcher.cpp:545;
+ *                  25 :404);  pass max_dist_exclusive = 257 to disable the cut-off
+ *   out_dist[i] = that minimum, or 257 when out_idx[i] == -1
+ * gate may be NULL (plain NQ x NT). Host-pointer form: copies in, runs, copies out, synchronises. */
+int svi_match_hamming256(svi_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                         const svi_gate* gate, int max_dist_exclusive,
+                         int32_t* out_idx, int32_t* out_dist);
+
+/* Device-resident, batched form: `batch` independent frame pairs laid out back to back
+ * (q: batch*nq*32 B, t: batch*nt*32 B, gate arrays likewise, outputs batch*nq). All pointers,
+ * including those inside *gate (the struct itself is read on the host), are device pointers.
+ * Asynchronous on the handle's stream. */
+int svi_match_hamming256_dev(svi_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                             int batch, const svi_gate* gate, int max_dist_exclusive,
+                             int32_t* out_idx, int32_t* out_dist);
+
+/* dist[i] = popcount(a_i ^ b_i), i < n  (cv::norm(a,b,NORM_HAMMING) batched). */
+int svi_hamming256_pairs(svi_matcher* m, const uint8_t* a, const uint8_t* b, int n, int32_t* dist);
+int svi_hamming256_pairs_dev(svi_matcher* m, const uint8_t* a, const uint8_t* b, int n, int32_t* dist);
+
+/* CTriangulator::getPointInLEFT batched: f32 pixel pairs -> f64 camera points.
+ *   ok[i] = 0 and xyz untouched(0) iff uL - uR < min_disparity (0.01, CTriangulator.h:21)
+ *   z = duR_flipped/(uL-uR), x = z (uL-cx)/f, y = z (vL-cy)/f   with duR_flipped = -P_R(0,3). */
+int svi_triangulate_rectified(svi_matcher* m, double f, double cx, double cy, double duR_flipped,
+                              double min_disparity, const float* uvL, const float* uvR, int n,
+                              double* xyz, uint8_t* ok);
+int svi_triangulate_rectified_dev(svi_matcher* m, double f, double cx, double cy, double duR_flipped,
+                                  double min_disparity, const float* uvL, const float* uvR, int n,
+                                  double* xyz, uint8_t* ok);
+
+/* Fused stereo step (a-1 + a-2 + a-3 of SURVEY.md §8a): gated match with the match's right pixel
+ * fed straight into the triangulation; out_xyz[i] valid iff out_idx[i] >= 0 && ok[i]. */
+int svi_match_triangulate_dev(svi_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt,
+                              int batch, const svi_gate* gate, int max_dist_exclusive,
+                              double f, double cx, double cy, double duR_flipped, double min_disparity,
+                              int32_t* out_idx, int32_t* out_dist, double* out_xyz, uint8_t* ok);
+
+/* ------------------------------------------------------------------------------------------
+ * Bundle adjustment — replaces the g2o::SparseOptimizer m_cOptimizerSparse of Cg2oOptimizer
+ * (Cg2oOptimizer.h:80) together with its solver stack (Cg2oOptimizer.cpp:83-89).
+ * Vertex ids follow the reference: landmark id = uID, pose id = uID + 1e6 (Cg2oOptimizer.h:83);
+ * variables are ordered by ascending id like g2o's index mapping.
+ * Poses are LEFT->WORLD isometries (Cg2oOptimizer.cpp:1232-1237) given as 12 doubles:
+ * R row-major (9) then t (3).
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct svi_ba svi_ba;
+
+typedef struct svi_ba_options {
+    /* g2o::ParameterCamera Kcam (Cg2oOptimizer.cpp:106) */
+    double fx, fy, cx, cy;
+    /* CStereoCamera::m_dBaselineMeters (CStereoCamera.h:28); used by the disparity measurement */
+    double baseline_m;
+    /* RobustKernelCauchy delta (g2o default 1.0; Cg2oOptimizer.cpp:1018,1042,1070) */
+    double cauchy_delta;
+    /* g2o::OptimizationAlgorithmLevenberg defaults */
+    double lm_tau;              /* 1e-5 */
+    double lm_good_step_lower;  /* 1/3  */
+    double lm_good_step_upper;  /* 2/3  */
+    int    lm_max_trials;       /* 10   */
+    /* _setLandmarkMeasurementsWORLD thresholds on squared norms (Cg2oOptimizer.h:92-94) */
+    double max_depth_xyz_l2;        /* 10    */
+    double max_depth_uvdepth_l2;    /* 50    */
+    double max_depth_uvdisp_l2;     /* 10000 */
+    double sane_position_l2;        /* 1e12 (Cg2oOptimizer.h:95) */
+    /* placement */
+    int    device;
+    void*  stream;              /* NULL: own stream */
+    /* landmark sharding: this handle owns the landmarks whose slot falls in the
+     * rank-th of n_ranks contiguous, edge-balanced ranges; pose-only edges belong to rank 0. */
+    int    rank;
+    int    n_ranks;
+    /* record hipEvents around every phase (svi_ba_get_phase_times) */
+    int    profile;
+    /* reduced camera system tile edge (multiple of 48; 0 = default 96) */
+    int    chol_tile;
+} svi_ba_options;
+
+void svi_ba_options_default(svi_ba_options* o);
+
+int svi_ba_create(const svi_ba_options* o, svi_ba** out);
+int svi_ba_destroy(svi_ba* ba);
+
+/* --- graph construction (host side, before svi_ba_initialize) ----------------------------- */
+int svi_ba_add_pose(svi_ba* ba, int64_t id, const double T[12], int fixed);
+int svi_ba_add_landmark(svi_ba* ba, int64_t id, const double p[3], int fixed);
+/* EdgeSE3PointXYZ / EdgeSE3PointXYZDepth / EdgeSE3PointXYZDisparity with identity offset
+ * (factories at Cg2oOptimizer.cpp:999-1073). info_upper = upper triangle row-major
+ * (00 01 02 11 12 22); the reference only ever sets the diagonal. robust != 0: Cauchy. */
+int svi_ba_add_edge_xyz(svi_ba* ba, int64_t pose_id, int64_t lm_id, const double z[3],
+                        const double info_upper[6], int robust);
+int svi_ba_add_edge_depth(svi_ba* ba, int64_t pose_id, int64_t lm_id, const double z[3],
+                          const double info_upper[6], int robust);
+int svi_ba_add_edge_disparity(svi_ba* ba, int64_t pose_id, int64_t lm_id, const double z[3],
+                              const double info_upper[6], int robust);
+/* bulk form of the three above: type[i] in {0 xyz, 1 depth, 2 disparity} */
+int svi_ba_add_edges_bulk(svi_ba* ba, int64_t n, const int32_t* type, const int64_t* pose_id,
+                          const int64_t* lm_id, const double* z /*n x 3*/,
+                          const double* info_upper /*n x 6*/, const int32_t* robust);
+/* EdgeSE3 odometry (Cg2oOptimizer.cpp:1248-1266); Z = measured X_i^-1 X_j (12 doubles),
+ * info_upper = 21 doubles (upper triangle row-major of the 6x6). */
+int svi_ba_add_edge_se3(svi_ba* ba, int64_t id_i, int64_t id_j, const double Z[12],
+                        const double info_upper[21], int robust);
+/* EdgeSE3LinearAcceleration (edge_se3_linear_acceleration.cpp:106-116); off = IMU->LEFT offset
+ * (12 doubles, NULL = identity). */
+int svi_ba_add_edge_accel(svi_ba* ba, int64_t pose_id, const double a[3], const double off[12],
+                          const double info_upper[6]);
+/* EdgePointXYZ landmark closure (Cg2oOptimizer.cpp:448-458): e = p_j - p_i - z. One of the two
+ * landmarks must be fixed (the reference fixes the reference landmark, :445). */
+int svi_ba_add_edge_lm_lm(svi_ba* ba, int64_t id_i, int64_t id_j, const double z[3],
+                          const double info_upper[6], int robust);
+
+/* --- reference-shaped construction (the rules of Cg2oOptimizer) --------------------------- */
+/* _setAndgetPose (Cg2oOptimizer.cpp:1229-1290) + _getEdgeLinearAcceleration (:982-997):
+ * adds the pose vertex (translation shifted by `shift`, NULL = 0), the odometry edge from
+ * `from_id` with measurement = current relative estimate and information
+ * 1e5*diag(s,s,s,1,1,1), s = 1/(1+|t_ij|^2), and the gravity edge carrying accel (NULL = 0). */
+int svi_ba_add_keyframe(svi_ba* ba, int64_t id, int64_t from_id, const double T_left_to_world[12],
+                        const double shift[3], const double accel[3]);
+/* _setLandmarkMeasurementsWORLD (Cg2oOptimizer.cpp:1383-1466): for each measurement of a
+ * landmark already in the graph apply the consistency gate 0.75 < |X^-1 l|^2/|p_m|^2 < 1.25 and
+ * choose XYZ / UV-depth / UV-disparity by |p_m|^2 (10 / 50 / 10000), information from w = 1/z_m.
+ * uv_left/uv_right: n x 2 float (cv::Point2f), xyz_left: n x 3 double.
+ * stored[3] (nullable) receives the number of edges of each kind that were added. */
+int svi_ba_add_measurements(svi_ba* ba, int64_t pose_id, int64_t n, const int64_t* lm_id,
+                            const float* uv_left, const float* uv_right, const double* xyz_left,
+                            int64_t stored[3]);
+
+/* --- optimisation -------------------------------------------------------------------------- */
+/* g2o initializeOptimization(): freeze the graph, build the device structures, upload. */
+int svi_ba_initialize(svi_ba* ba);
+/* one g2o SparseOptimizer::optimize(iterations) block: structure + lambda re-initialised,
+ * returns the number of LM iterations executed in *performed (nullable). */
+int svi_ba_optimize(svi_ba* ba, int iterations, int* performed);
+/* Cg2oOptimizer::_optimizeUnLimited (Cg2oOptimizer.cpp:954-980):
+ *   optimize(first); prev = 1.1*chi2; while (chi2/prev < ratio) { prev = chi2; optimize(block); }
+ * nominal = first + block*k (the reference's counter), executed = LM iterations really run. */
+int svi_ba_optimize_until(svi_ba* ba, double ratio, int first, int block,
+                          uint64_t* nominal, uint64_t* executed);
+/* g2o OptimizableGraph::chi2(): plain sum e' Omega e with the most recently evaluated errors;
+ * robust: g2o activeRobustChi2(). Either pointer may be NULL. */
+int svi_ba_chi2(svi_ba* ba, double* plain, double* robust);
+/* current LM damping (after the last optimize) */
+int svi_ba_lambda(svi_ba* ba, double* lambda);
+
+/* --- results -------------------------------------------------------------------------------- */
+int svi_ba_get_pose(svi_ba* ba, int64_t id, double T[12]);
+int svi_ba_get_landmark(svi_ba* ba, int64_t id, double p[3]);
+/* all vertices in ascending-id order; ids nullable */
+int svi_ba_num_poses(svi_ba* ba, int64_t* n);
+int svi_ba_num_landmarks(svi_ba* ba, int64_t* n);
+int svi_ba_num_edges(svi_ba* ba, int64_t* n);
+int svi_ba_get_poses(svi_ba* ba, int64_t* ids, double* T /*n x 12*/);
+int svi_ba_get_landmarks(svi_ba* ba, int64_t* ids, double* p /*n x 3*/);
+/* _applyOptimizationToLandmarks rule (Cg2oOptimizer.cpp:1468-1512): remove every landmark with
+ * |p|^2 >= sane_position_l2 together with its edges; *removed (nullable) = how many. The graph
+ * must be re-initialised afterwards. */
+int svi_ba_prune_diverged(svi_ba* ba, int64_t* removed);
+
+/* --- .g2o text interchange (Cg2oOptimizer.cpp:495-497, 514) ------------------------------- */
+int svi_ba_load_g2o(svi_ba* ba, const char* path);
+int svi_ba_save_g2o(svi_ba* ba, const char* path);
+
+/* --- multi-GPU hook ------------------------------------------------------------------------ */
+/* Sum-all-reduce of `count` doubles living at device pointer `buf`, in place, ordered on
+ * `stream` (a hipStream_t). Return 0 on success. The harness implements it with
+ * torch.distributed / RCCL (svi_mapper_amd/dist.py); with n_ranks == 1 it is never called. */
+typedef int (*svi_allreduce_fn)(void* user, void* buf, size_t count, void* stream);
+int svi_ba_set_allreduce(svi_ba* ba, svi_allreduce_fn fn, void* user);
+
+/* --- instrumentation ----------------------------------------------------------------------- */
+enum svi_ba_phase {
+    SVI_PH_LINEARIZE_LM   = 0, /* K2: landmark-major Jacobian sweep -> H_ll, b_l, H_pl        */
+    SVI_PH_LINEARIZE_POSE = 1, /* K3: pose-major Jacobian sweep -> H_pp, b_p                  */
+    SVI_PH_POSE_EDGES     = 2, /* odometry / gravity / landmark-closure edges                 */
+    SVI_PH_SCHUR          = 3, /* K4: per-landmark inverse + windowed S, g contributions      */
+    SVI_PH_ASSEMBLE       = 4, /* K4b: ordered reduction of the windows into the tile store  */
+    SVI_PH_ALLREDUCE      = 5, /* RCCL hook                                                   */
+    SVI_PH_CHOLESKY       = 6, /* K5: tile-sparse LL' + triangular solves                     */
+    SVI_PH_BACKSUB_UPDATE = 7, /* K6+K7: landmark back-substitution, oplus                    */
+    SVI_PH_CHI2           = 8, /* K8: error sweep                                             */
+    SVI_PH_COUNT          = 9
+};
+/* accumulated device milliseconds and launch counts per phase since the last reset
+ * (only when options.profile != 0) */
+int svi_ba_get_phase_times(svi_ba* ba, double ms[SVI_PH_COUNT], int64_t calls[SVI_PH_COUNT]);
+int svi_ba_reset_phase_times(svi_ba* ba);
+
+/* sizes of the device structures, for roofline accounting */
+typedef struct svi_ba_stats {
+    int64_t n_poses, n_poses_free, n_landmarks, n_landmarks_local;
+    int64_t n_edges_proj, n_edges_proj_local, n_edges_se3, n_edges_accel, n_edges_lmlm;
+    int64_t n_schur_tiles, n_window_blocks;    /* K4 decomposition */
+    int64_t chol_n, chol_tile, chol_tiles_nnz; /* reduced system */
+    int64_t reduce_doubles;                    /* payload of one all-reduce */
+    double  chol_flops;                        /* of one factorisation on the tile structure */
+    uint64_t lm_iterations, lm_trials, chol_failures;
+} svi_ba_stats;
+int svi_ba_get_stats(svi_ba* ba, svi_ba_stats* s);
+
+/* --- debug / parity taps (device state -> host; small graphs) ------------------------------ */
+/* per projection edge, in insertion order: error (3) and Jacobians at the current estimate */
+int svi_ba_debug_edge_jacobians(svi_ba* ba, double* err /*E x 3*/, double* J_pose /*E x 18*/,
+                                double* J_lm /*E x 9*/);
+/* dense reduced system of the last linearisation with damping `lambda`:
+ * S (n x n row-major, full symmetric) and g (n), n = 6 * free poses; *n_out receives n */
+int svi_ba_debug_reduced_system(svi_ba* ba, double lambda, double* S, double* g, int64_t cap,
+                                int64_t* n_out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SVI_HOT_H */

@@ -1,0 +1,392 @@
+"""ctypes loader for the CPU oracle (oracle_match.c, oracle_ba.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  Nothing under svi_mapper_amd/ may import this module.
+PARITY UNPINNED (see the C file headers and DESIGN.md "Oracle").
+
+The Python classes deliberately expose the same method names as
+svi_mapper_amd.BundleAdjuster / HammingMatcher so the parity tests drive both alike.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+_f64p = C.POINTER(C.c_double)
+_f32p = C.POINTER(C.c_float)
+_i64p = C.POINTER(C.c_int64)
+_i32p = C.POINTER(C.c_int32)
+_u8p = C.POINTER(C.c_uint8)
+
+
+def build(native=False):
+    """Compile the oracle with gcc. native=True builds liboracle_native.so with -march=native
+    (used by the timed cpu_baseline leg on the box it runs on)."""
+    if native:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "MARCH=native", "OUT=liboracle_native.so"])
+        return os.path.join(_HERE, "liboracle_native.so")
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+    return os.path.join(_HERE, "liboracle.so")
+
+
+def _p(a, t):
+    return a.ctypes.data_as(t) if a is not None else None
+
+
+def load(path=None):
+    global _LIB
+    if _LIB is not None and path is None:
+        return _LIB
+    if path is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+    lib = C.CDLL(path)
+    lib.orc_ba_create.restype = C.c_void_p
+    lib.orc_ba_create.argtypes = [C.c_double] * 5
+    lib.orc_ba_destroy.argtypes = [C.c_void_p]
+    lib.orc_ba_set_lm.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double]
+    lib.orc_ba_set_accel_numeric.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_ba_add_pose.argtypes = [C.c_void_p, C.c_int64, _f64p, C.c_int]
+    lib.orc_ba_add_landmark.argtypes = [C.c_void_p, C.c_int64, _f64p, C.c_int]
+    lib.orc_ba_add_edge_proj.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, _f64p, _f64p, C.c_int]
+    lib.orc_ba_add_edge_se3.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _f64p, _f64p, C.c_int]
+    lib.orc_ba_add_edge_accel.argtypes = [C.c_void_p, C.c_int64, _f64p, _f64p, _f64p]
+    lib.orc_ba_add_edge_lm_lm.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _f64p, _f64p, C.c_int]
+    lib.orc_ba_add_keyframe.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _f64p, _f64p, _f64p]
+    lib.orc_ba_add_measurements.argtypes = [C.c_void_p, C.c_int64, C.c_int64, _i64p, _f32p, _f32p, _f64p, _i64p]
+    lib.orc_ba_initialize.argtypes = [C.c_void_p]
+    lib.orc_ba_optimize.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_ba_optimize_until.argtypes = [C.c_void_p, C.c_double, C.c_int, C.c_int,
+                                          C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+    lib.orc_ba_chi2.argtypes = [C.c_void_p, _f64p, _f64p]
+    lib.orc_ba_last_plain_chi2.restype = C.c_double
+    lib.orc_ba_last_plain_chi2.argtypes = [C.c_void_p]
+    lib.orc_ba_lambda.restype = C.c_double
+    lib.orc_ba_lambda.argtypes = [C.c_void_p]
+    for f in ("num_poses", "num_landmarks", "num_edges", "num_aux", "system_size"):
+        getattr(lib, "orc_ba_" + f).restype = C.c_int64
+        getattr(lib, "orc_ba_" + f).argtypes = [C.c_void_p]
+    for f in ("iterations", "trials"):
+        getattr(lib, "orc_ba_" + f).restype = C.c_uint64
+        getattr(lib, "orc_ba_" + f).argtypes = [C.c_void_p]
+    lib.orc_ba_get_pose.argtypes = [C.c_void_p, C.c_int64, _f64p]
+    lib.orc_ba_get_landmark.argtypes = [C.c_void_p, C.c_int64, _f64p]
+    lib.orc_ba_get_poses.argtypes = [C.c_void_p, _i64p, _f64p]
+    lib.orc_ba_get_landmarks.argtypes = [C.c_void_p, _i64p, _f64p]
+    lib.orc_ba_get_edges.argtypes = [C.c_void_p, _i32p, _i64p, _i64p, _f64p, _f64p]
+    lib.orc_ba_get_aux.argtypes = [C.c_void_p, _i32p, _i64p, _i64p, _f64p, _f64p]
+    lib.orc_ba_edge_jacobians.argtypes = [C.c_void_p, _f64p, _f64p, _f64p]
+    lib.orc_ba_dense_system.restype = C.c_int64
+    lib.orc_ba_dense_system.argtypes = [C.c_void_p, _f64p, _f64p, C.c_int64, _i32p, _i32p]
+    lib.orc_ba_trace.argtypes = [C.c_void_p, _f64p, C.c_int]
+    lib.orc_ba_trace_clear.argtypes = [C.c_void_p]
+    lib.orc_ba_prune_diverged.restype = C.c_int64
+    lib.orc_ba_prune_diverged.argtypes = [C.c_void_p]
+    lib.orc_se3_edge.argtypes = [_f64p] * 6
+    lib.orc_se3_oplus.argtypes = [_f64p] * 3
+    lib.orc_match_hamming256.argtypes = [_u8p, C.c_int, _u8p, C.c_int, C.c_int, _f32p, _f32p, _f32p, _f32p,
+                                         C.c_float, C.c_int, _i32p, _i32p]
+    lib.orc_hamming256_pairs.argtypes = [_u8p, _u8p, C.c_int, _i32p]
+    lib.orc_triangulate_rectified.argtypes = [C.c_double] * 5 + [_f32p, _f32p, C.c_int, _f64p, _u8p]
+    if path.endswith("liboracle.so"):
+        _LIB = lib
+    return lib
+
+
+# ------------------------------------------------------------------------------------------------
+# matcher
+# ------------------------------------------------------------------------------------------------
+def match_hamming256(q, t, gate=None, max_dist_exclusive=257, lib=None):
+    """gate = dict(q_uv, t_uv, q_umin, q_umax, v_tol) or None. Returns (idx int32, dist int32)."""
+    lib = lib or load()
+    q = np.ascontiguousarray(q, np.uint8).reshape(-1, 32)
+    t = np.ascontiguousarray(t, np.uint8).reshape(-1, 32)
+    idx = np.empty(len(q), np.int32)
+    dist = np.empty(len(q), np.int32)
+    if gate is not None:
+        quv = np.ascontiguousarray(gate["q_uv"], np.float32)
+        tuv = np.ascontiguousarray(gate["t_uv"], np.float32)
+        umin = np.ascontiguousarray(gate["q_umin"], np.float32)
+        umax = np.ascontiguousarray(gate["q_umax"], np.float32)
+        lib.orc_match_hamming256(_p(q, _u8p), len(q), _p(t, _u8p), len(t), 1, _p(quv, _f32p), _p(tuv, _f32p),
+                                 _p(umin, _f32p), _p(umax, _f32p), float(gate.get("v_tol", 0.0)),
+                                 int(max_dist_exclusive), _p(idx, _i32p), _p(dist, _i32p))
+    else:
+        lib.orc_match_hamming256(_p(q, _u8p), len(q), _p(t, _u8p), len(t), 0, None, None, None, None, 0.0,
+                                 int(max_dist_exclusive), _p(idx, _i32p), _p(dist, _i32p))
+    return idx, dist
+
+
+def hamming256_pairs(a, b, lib=None):
+    lib = lib or load()
+    a = np.ascontiguousarray(a, np.uint8).reshape(-1, 32)
+    b = np.ascontiguousarray(b, np.uint8).reshape(-1, 32)
+    d = np.empty(len(a), np.int32)
+    lib.orc_hamming256_pairs(_p(a, _u8p), _p(b, _u8p), len(a), _p(d, _i32p))
+    return d
+
+
+def triangulate_rectified(f, cx, cy, duR_flipped, uvL, uvR, min_disparity=0.01, lib=None):
+    lib = lib or load()
+    uvL = np.ascontiguousarray(uvL, np.float32).reshape(-1, 2)
+    uvR = np.ascontiguousarray(uvR, np.float32).reshape(-1, 2)
+    xyz = np.zeros((len(uvL), 3), np.float64)
+    ok = np.zeros(len(uvL), np.uint8)
+    lib.orc_triangulate_rectified(f, cx, cy, duR_flipped, min_disparity, _p(uvL, _f32p), _p(uvR, _f32p),
+                                  len(uvL), _p(xyz, _f64p), _p(ok, _u8p))
+    return xyz, ok
+
+
+def se3_edge(Xi, Xj, Z, jac=True, lib=None):
+    lib = lib or load()
+    Xi, Xj, Z = (np.ascontiguousarray(a, np.float64).reshape(12) for a in (Xi, Xj, Z))
+    e = np.zeros(6)
+    if jac:
+        Ji = np.zeros((6, 6))
+        Jj = np.zeros((6, 6))
+        lib.orc_se3_edge(_p(Xi, _f64p), _p(Xj, _f64p), _p(Z, _f64p), _p(e, _f64p), _p(Ji, _f64p), _p(Jj, _f64p))
+        return e, Ji, Jj
+    lib.orc_se3_edge(_p(Xi, _f64p), _p(Xj, _f64p), _p(Z, _f64p), _p(e, _f64p), None, None)
+    return e
+
+
+def se3_oplus(T, d, lib=None):
+    lib = lib or load()
+    T = np.ascontiguousarray(T, np.float64).reshape(12)
+    d = np.ascontiguousarray(d, np.float64).reshape(6)
+    out = np.zeros(12)
+    lib.orc_se3_oplus(_p(T, _f64p), _p(d, _f64p), _p(out, _f64p))
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# bundle adjustment
+# ------------------------------------------------------------------------------------------------
+class OracleBA:
+    """Same surface as svi_mapper_amd.BundleAdjuster, computed by the CPU restatement."""
+
+    def __init__(self, fx, fy, cx, cy, baseline_m, lib=None, **lm):
+        self.lib = lib or load()
+        self.h = C.c_void_p(self.lib.orc_ba_create(fx, fy, cx, cy, baseline_m))
+        if lm:
+            self.lib.orc_ba_set_lm(self.h, lm.get("lm_tau", 1e-5), lm.get("lm_good_step_lower", 1 / 3),
+                                   lm.get("lm_good_step_upper", 2 / 3), lm.get("lm_max_trials", 10),
+                                   lm.get("cauchy_delta", 1.0))
+
+    def close(self):
+        if self.h:
+            self.lib.orc_ba_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @staticmethod
+    def _d(a, n=None):
+        a = np.ascontiguousarray(a, np.float64)
+        if n is not None:
+            a = a.reshape(n)
+        return a
+
+    def _chk(self, rc, what):
+        if rc != 0:
+            raise ValueError("oracle: %s failed (%d)" % (what, rc))
+
+    def set_accel_numeric(self, on):
+        self.lib.orc_ba_set_accel_numeric(self.h, int(on))
+
+    def add_pose(self, id, T, fixed=False):
+        T = self._d(T, 12)
+        self._chk(self.lib.orc_ba_add_pose(self.h, int(id), _p(T, _f64p), int(fixed)), "add_pose")
+
+    def add_landmark(self, id, p, fixed=False):
+        p = self._d(p, 3)
+        self._chk(self.lib.orc_ba_add_landmark(self.h, int(id), _p(p, _f64p), int(fixed)), "add_landmark")
+
+    def add_landmarks(self, ids, p, fixed=False):
+        p = self._d(p).reshape(-1, 3)
+        for i, pid in enumerate(ids):
+            self._chk(self.lib.orc_ba_add_landmark(self.h, int(pid), _p(p[i], _f64p), int(fixed)), "add_landmark")
+
+    def add_edges_bulk(self, type, pose_id, lm_id, z, info_upper, robust):
+        z = self._d(z).reshape(-1, 3)
+        info = self._d(info_upper).reshape(-1, 6)
+        robust = np.broadcast_to(np.asarray(robust, np.int32), (len(z),))
+        for i in range(len(z)):
+            self._chk(self.lib.orc_ba_add_edge_proj(self.h, int(type[i]), int(pose_id[i]), int(lm_id[i]),
+                                                    _p(z[i], _f64p), _p(info[i], _f64p), int(robust[i])), "add_edge")
+
+    def add_edge_se3(self, i, j, Z, info_upper, robust=False):
+        Z = self._d(Z, 12)
+        info = self._d(info_upper, 21)
+        self._chk(self.lib.orc_ba_add_edge_se3(self.h, int(i), int(j), _p(Z, _f64p), _p(info, _f64p), int(robust)),
+                  "add_edge_se3")
+
+    def add_edge_accel(self, pose_id, a, off=None, info_upper=(1, 0, 0, 1, 0, 1)):
+        a = self._d(a, 3)
+        info = self._d(info_upper, 6)
+        off = self._d(off, 12) if off is not None else None
+        self._chk(self.lib.orc_ba_add_edge_accel(self.h, int(pose_id), _p(a, _f64p), _p(off, _f64p), _p(info, _f64p)),
+                  "add_edge_accel")
+
+    def add_edge_lm_lm(self, i, j, z, info_upper, robust=True):
+        z = self._d(z, 3)
+        info = self._d(info_upper, 6)
+        self._chk(self.lib.orc_ba_add_edge_lm_lm(self.h, int(i), int(j), _p(z, _f64p), _p(info, _f64p), int(robust)),
+                  "add_edge_lm_lm")
+
+    def add_keyframe(self, id, from_id, T, shift=None, accel=None):
+        T = self._d(T, 12)
+        shift = self._d(shift, 3) if shift is not None else None
+        accel = self._d(accel, 3) if accel is not None else None
+        self._chk(self.lib.orc_ba_add_keyframe(self.h, int(id), int(from_id), _p(T, _f64p), _p(shift, _f64p),
+                                               _p(accel, _f64p)), "add_keyframe")
+
+    def add_measurements(self, pose_id, lm_id, uv_left, uv_right, xyz_left):
+        lm_id = np.ascontiguousarray(lm_id, np.int64)
+        uvl = np.ascontiguousarray(uv_left, np.float32).reshape(-1, 2)
+        uvr = np.ascontiguousarray(uv_right, np.float32).reshape(-1, 2)
+        xyz = self._d(xyz_left).reshape(-1, 3)
+        stored = np.zeros(3, np.int64)
+        self._chk(self.lib.orc_ba_add_measurements(self.h, int(pose_id), len(lm_id), _p(lm_id, _i64p), _p(uvl, _f32p),
+                                                   _p(uvr, _f32p), _p(xyz, _f64p), _p(stored, _i64p)),
+                  "add_measurements")
+        return stored
+
+    def initialize(self):
+        self._chk(self.lib.orc_ba_initialize(self.h), "initialize")
+
+    def optimize(self, iterations):
+        r = self.lib.orc_ba_optimize(self.h, int(iterations))
+        if r < 0:
+            raise ValueError("oracle: optimize before initialize")
+        return r
+
+    def optimize_until(self, ratio=0.99, first=1, block=10):
+        nom = C.c_uint64(0)
+        exe = C.c_uint64(0)
+        self._chk(self.lib.orc_ba_optimize_until(self.h, ratio, first, block, C.byref(nom), C.byref(exe)),
+                  "optimize_until")
+        return nom.value, exe.value
+
+    def chi2(self):
+        p = C.c_double(0)
+        r = C.c_double(0)
+        self.lib.orc_ba_chi2(self.h, C.byref(p), C.byref(r))
+        return p.value, r.value
+
+    @property
+    def last_plain_chi2(self):
+        return self.lib.orc_ba_last_plain_chi2(self.h)
+
+    @property
+    def lm_lambda(self):
+        return self.lib.orc_ba_lambda(self.h)
+
+    @property
+    def num_poses(self):
+        return self.lib.orc_ba_num_poses(self.h)
+
+    @property
+    def num_landmarks(self):
+        return self.lib.orc_ba_num_landmarks(self.h)
+
+    @property
+    def num_edges(self):
+        return self.lib.orc_ba_num_edges(self.h)
+
+    @property
+    def system_size(self):
+        return self.lib.orc_ba_system_size(self.h)
+
+    @property
+    def iterations(self):
+        return self.lib.orc_ba_iterations(self.h)
+
+    @property
+    def trials(self):
+        return self.lib.orc_ba_trials(self.h)
+
+    def get_pose(self, id):
+        T = np.zeros(12)
+        self._chk(self.lib.orc_ba_get_pose(self.h, int(id), _p(T, _f64p)), "get_pose")
+        return T
+
+    def get_landmark(self, id):
+        p = np.zeros(3)
+        self._chk(self.lib.orc_ba_get_landmark(self.h, int(id), _p(p, _f64p)), "get_landmark")
+        return p
+
+    def get_poses(self):
+        """(ids, T[n,12]) sorted by ascending id (the C-ABI's order)."""
+        n = self.num_poses
+        ids = np.zeros(n, np.int64)
+        T = np.zeros((n, 12))
+        self.lib.orc_ba_get_poses(self.h, _p(ids, _i64p), _p(T, _f64p))
+        o = np.argsort(ids, kind="stable")
+        return ids[o], T[o]
+
+    def get_landmarks(self):
+        n = self.num_landmarks
+        ids = np.zeros(n, np.int64)
+        p = np.zeros((n, 3))
+        self.lib.orc_ba_get_landmarks(self.h, _p(ids, _i64p), _p(p, _f64p))
+        o = np.argsort(ids, kind="stable")
+        return ids[o], p[o]
+
+    def get_edges(self):
+        n = self.num_edges
+        ty = np.zeros(n, np.int32)
+        pid = np.zeros(n, np.int64)
+        lid = np.zeros(n, np.int64)
+        z = np.zeros((n, 3))
+        info = np.zeros((n, 6))
+        self.lib.orc_ba_get_edges(self.h, _p(ty, _i32p), _p(pid, _i64p), _p(lid, _i64p), _p(z, _f64p), _p(info, _f64p))
+        return ty, pid, lid, z, info
+
+    def get_aux(self):
+        n = self.lib.orc_ba_num_aux(self.h)
+        ty = np.zeros(n, np.int32)
+        ia = np.zeros(n, np.int64)
+        ib = np.zeros(n, np.int64)
+        z = np.zeros((n, 12))
+        info = np.zeros((n, 21))
+        self.lib.orc_ba_get_aux(self.h, _p(ty, _i32p), _p(ia, _i64p), _p(ib, _i64p), _p(z, _f64p), _p(info, _f64p))
+        return ty, ia, ib, z, info
+
+    def edge_jacobians(self):
+        n = self.num_edges
+        e = np.zeros((n, 3))
+        Jp = np.zeros((n, 3, 6))
+        Jl = np.zeros((n, 3, 3))
+        self.lib.orc_ba_edge_jacobians(self.h, _p(e, _f64p), _p(Jp, _f64p), _p(Jl, _f64p))
+        return e, Jp, Jl
+
+    def dense_system(self):
+        """H (n,n), b (n), pose_col (by insertion), lm_col (by insertion) at the current estimate."""
+        n = self.system_size
+        H = np.zeros((n, n))
+        b = np.zeros(n)
+        pc = np.zeros(self.num_poses, np.int32)
+        lc = np.zeros(self.num_landmarks, np.int32)
+        r = self.lib.orc_ba_dense_system(self.h, _p(H, _f64p), _p(b, _f64p), n, _p(pc, _i32p), _p(lc, _i32p))
+        if r < 0:
+            raise ValueError("oracle: dense_system failed")
+        return H, b, pc, lc
+
+    def trace(self):
+        n = self.lib.orc_ba_trace(self.h, None, 0)
+        out = np.zeros(n)
+        self.lib.orc_ba_trace(self.h, _p(out, _f64p), n)
+        return out.reshape(-1, 5)
+
+    def prune_diverged(self):
+        return self.lib.orc_ba_prune_diverged(self.h)

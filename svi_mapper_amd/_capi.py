@@ -1,0 +1,150 @@
+"""ctypes binding of libsvi_hot.so (include/svi_hot.h).
+
+This module is deliberately thin: it loads the in-tree shared library and declares argument
+types. There is NO fallback: if the library is missing, import fails; if no gfx950 device is
+visible, every compute entry point returns SVI_ERR_NO_DEVICE and the wrappers raise SviError.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libsvi_hot.so")
+
+SVI_OK = 0
+SVI_PH_NAMES = ("linearize_lm", "linearize_pose", "pose_edges", "schur", "assemble", "allreduce",
+                "cholesky", "backsub_update", "chi2")
+
+f64p = C.POINTER(C.c_double)
+f32p = C.POINTER(C.c_float)
+i64p = C.POINTER(C.c_int64)
+i32p = C.POINTER(C.c_int32)
+u8p = C.POINTER(C.c_uint8)
+u64p = C.POINTER(C.c_uint64)
+vp = C.c_void_p
+
+
+class SviError(RuntimeError):
+    def __init__(self, status, where, detail):
+        super().__init__("%s: %s (%d)%s" % (where, _status_string(status), status, (": " + detail) if detail else ""))
+        self.status = status
+
+
+class Gate(C.Structure):
+    _fields_ = [("q_uv", vp), ("t_uv", vp), ("q_umin", vp), ("q_umax", vp), ("v_tol", C.c_float)]
+
+
+class BaOptions(C.Structure):
+    _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
+                ("baseline_m", C.c_double), ("cauchy_delta", C.c_double), ("lm_tau", C.c_double),
+                ("lm_good_step_lower", C.c_double), ("lm_good_step_upper", C.c_double),
+                ("lm_max_trials", C.c_int),
+                ("max_depth_xyz_l2", C.c_double), ("max_depth_uvdepth_l2", C.c_double),
+                ("max_depth_uvdisp_l2", C.c_double), ("sane_position_l2", C.c_double),
+                ("device", C.c_int), ("stream", vp), ("rank", C.c_int), ("n_ranks", C.c_int),
+                ("profile", C.c_int), ("chol_tile", C.c_int)]
+
+
+class BaStats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in
+                ("n_poses", "n_poses_free", "n_landmarks", "n_landmarks_local", "n_edges_proj",
+                 "n_edges_proj_local", "n_edges_se3", "n_edges_accel", "n_edges_lmlm", "n_schur_tiles",
+                 "n_window_blocks", "chol_n", "chol_tile", "chol_tiles_nnz", "reduce_doubles")] + \
+               [("chol_flops", C.c_double), ("lm_iterations", C.c_uint64), ("lm_trials", C.c_uint64),
+                ("chol_failures", C.c_uint64)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, vp)
+
+# name -> (restype, argtypes); every symbol include/svi_hot.h declares
+SIGNATURES = {
+    "svi_status_string": (C.c_char_p, [C.c_int]),
+    "svi_last_error": (C.c_char_p, []),
+    "svi_version": (C.c_int, []),
+    "svi_device_count": (C.c_int, []),
+    "svi_matcher_create": (C.c_int, [C.c_int, vp, C.POINTER(vp)]),
+    "svi_matcher_destroy": (C.c_int, [vp]),
+    "svi_matcher_sync": (C.c_int, [vp]),
+    "svi_matcher_stream": (vp, [vp]),
+    "svi_match_hamming256": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.POINTER(Gate), C.c_int, vp, vp]),
+    "svi_match_hamming256_dev": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.POINTER(Gate), C.c_int, vp, vp]),
+    "svi_hamming256_pairs": (C.c_int, [vp, vp, vp, C.c_int, vp]),
+    "svi_hamming256_pairs_dev": (C.c_int, [vp, vp, vp, C.c_int, vp]),
+    "svi_triangulate_rectified": (C.c_int, [vp] + [C.c_double] * 5 + [vp, vp, C.c_int, vp, vp]),
+    "svi_triangulate_rectified_dev": (C.c_int, [vp] + [C.c_double] * 5 + [vp, vp, C.c_int, vp, vp]),
+    "svi_match_triangulate_dev": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.POINTER(Gate), C.c_int] +
+                                  [C.c_double] * 5 + [vp, vp, vp, vp]),
+    "svi_ba_options_default": (None, [C.POINTER(BaOptions)]),
+    "svi_ba_create": (C.c_int, [C.POINTER(BaOptions), C.POINTER(vp)]),
+    "svi_ba_destroy": (C.c_int, [vp]),
+    "svi_ba_add_pose": (C.c_int, [vp, C.c_int64, f64p, C.c_int]),
+    "svi_ba_add_landmark": (C.c_int, [vp, C.c_int64, f64p, C.c_int]),
+    "svi_ba_add_edge_xyz": (C.c_int, [vp, C.c_int64, C.c_int64, f64p, f64p, C.c_int]),
+    "svi_ba_add_edge_depth": (C.c_int, [vp, C.c_int64, C.c_int64, f64p, f64p, C.c_int]),
+    "svi_ba_add_edge_disparity": (C.c_int, [vp, C.c_int64, C.c_int64, f64p, f64p, C.c_int]),
+    "svi_ba_add_edges_bulk": (C.c_int, [vp, C.c_int64, i32p, i64p, i64p, f64p, f64p, i32p]),
+    "svi_ba_add_edge_se3": (C.c_int, [vp, C.c_int64, C.c_int64, f64p, f64p, C.c_int]),
+    "svi_ba_add_edge_accel": (C.c_int, [vp, C.c_int64, f64p, f64p, f64p]),
+    "svi_ba_add_edge_lm_lm": (C.c_int, [vp, C.c_int64, C.c_int64, f64p, f64p, C.c_int]),
+    "svi_ba_add_keyframe": (C.c_int, [vp, C.c_int64, C.c_int64, f64p, f64p, f64p]),
+    "svi_ba_add_measurements": (C.c_int, [vp, C.c_int64, C.c_int64, i64p, f32p, f32p, f64p, i64p]),
+    "svi_ba_initialize": (C.c_int, [vp]),
+    "svi_ba_optimize": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
+    "svi_ba_optimize_until": (C.c_int, [vp, C.c_double, C.c_int, C.c_int, u64p, u64p]),
+    "svi_ba_chi2": (C.c_int, [vp, f64p, f64p]),
+    "svi_ba_lambda": (C.c_int, [vp, f64p]),
+    "svi_ba_get_pose": (C.c_int, [vp, C.c_int64, f64p]),
+    "svi_ba_get_landmark": (C.c_int, [vp, C.c_int64, f64p]),
+    "svi_ba_num_poses": (C.c_int, [vp, i64p]),
+    "svi_ba_num_landmarks": (C.c_int, [vp, i64p]),
+    "svi_ba_num_edges": (C.c_int, [vp, i64p]),
+    "svi_ba_get_poses": (C.c_int, [vp, i64p, f64p]),
+    "svi_ba_get_landmarks": (C.c_int, [vp, i64p, f64p]),
+    "svi_ba_prune_diverged": (C.c_int, [vp, i64p]),
+    "svi_ba_load_g2o": (C.c_int, [vp, C.c_char_p]),
+    "svi_ba_save_g2o": (C.c_int, [vp, C.c_char_p]),
+    "svi_ba_set_allreduce": (C.c_int, [vp, ALLREDUCE_FN, vp]),
+    "svi_ba_get_phase_times": (C.c_int, [vp, f64p, i64p]),
+    "svi_ba_reset_phase_times": (C.c_int, [vp]),
+    "svi_ba_get_stats": (C.c_int, [vp, C.POINTER(BaStats)]),
+    "svi_ba_debug_edge_jacobians": (C.c_int, [vp, f64p, f64p, f64p]),
+    "svi_ba_debug_reduced_system": (C.c_int, [vp, C.c_double, f64p, f64p, C.c_int64, i64p]),
+}
+
+_lib = None
+
+
+def load_library(path=None):
+    """Load libsvi_hot.so and bind every declared symbol. Raises ImportError if it is missing."""
+    global _lib
+    if _lib is not None and path is None:
+        return _lib
+    p = path or LIB_PATH
+    if not os.path.exists(p):
+        raise ImportError("svi_mapper_amd: %s not found - build it with `python -c 'import __graft_entry__ as g; "
+                          "g.build()'` or `make -C svi_mapper_amd/csrc` (hipcc, gfx950). There is no CPU fallback." % p)
+    lib = C.CDLL(p)
+    missing = []
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            missing.append(name)
+            continue
+        fn.restype = res
+        fn.argtypes = args
+    if missing:  # header and library disagree: refuse to run on a partial ABI
+        raise ImportError("svi_mapper_amd: %s lacks symbols declared in include/svi_hot.h: %s" % (p, ", ".join(missing)))
+    if path is None:
+        _lib = lib
+    return lib
+
+
+def _status_string(status):
+    try:
+        return load_library().svi_status_string(int(status)).decode()
+    except Exception:
+        return "status"
+
+
+def check(status, where):
+    if status != SVI_OK:
+        raise SviError(status, where, load_library().svi_last_error().decode())

@@ -1,0 +1,158 @@
+// ba_device.h — HBM layout of the bundle-adjustment path and the launchers of its kernels.
+//
+// Everything the LM loop touches is resident on the device; the host only sees a handful of
+// scalars per trial (chi2, step scale, Cholesky status).
+//
+// Index spaces
+//   pose slot    s in [0, Pn)   poses in ascending id (g2o index-mapping order)
+//   reduced pose r in [0, Pf)   free poses only, same order; pose_red[s] = r or -1 (fixed)
+//   landmark     l in [0, Ll)   this rank's landmarks in ascending id (contiguous id range)
+//   lm-major edge e in [0, E)   this rank's projection edges sorted by (l, s)
+//   pose-major edge             the same edges sorted by (s, l)
+//   reduced system               n = 6*Pf scalars, tiled TS x TS (TS multiple of 48, default 96),
+//                                 only the lower block triangle is stored, only tiles that can be
+//                                 non-zero after fill-in ("tile-sparse")
+#pragma once
+#include <cstdint>
+
+namespace svi {
+
+enum : int { kTypeXYZ = 0, kTypeDepth = 1, kTypeDisparity = 2 };
+// e_flags bits
+enum : unsigned { kFlagTypeMask = 3u, kFlagRobust = 4u };
+
+constexpr int kLmBlockEdges = 256;   // lm-major kernels: one workgroup owns whole landmarks, <= 256 edges
+constexpr int kPoseChunk    = 1024;  // pose-major kernel: one workgroup sums <= 1024 edges of one pose
+constexpr int kMaxTile      = 96;
+
+struct BaDev {
+    // camera / robust kernel
+    double fx, fy, cx, cy, cauchy_delta;
+
+    // sizes
+    int Pn, Pf, Ll, E;
+    int n_lm_blocks;     // lm-major workgroups
+    int n_chunks;        // pose-major workgroups
+    int n_se3, n_accel, n_lmlm;
+    int info_planes;     // 3: all informations diagonal (only 00,11,22 stored), 6: upper triangles
+
+    // state (double buffered: [cur] is the accepted estimate, [cur^1] the trial)
+    double* pose[2];     // [Pn][12]  R row-major (9), t (3)
+    double* lm[2];       // [Ll][3]
+    const int* pose_red; // [Pn]
+    const uint8_t* lm_fixed; // [Ll]
+
+    // lm-major projection edges (SoA)
+    const int*     e_pose;  // [E] pose slot
+    const int*     e_lm;    // [E] landmark
+    const uint8_t* e_flags; // [E]
+    const double*  e_z;     // [3][E]
+    const double*  e_info;  // [info_planes][E]
+    const int*     lm_ptr;  // [Ll+1] edges of landmark l
+    const int*     lb_lm;   // [n_lm_blocks+1] landmarks of lm-major workgroup b
+    // pose-major copy
+    const int*     pm_lm;    // [E]
+    const uint8_t* pm_flags; // [E]
+    const double*  pm_z;     // [3][E]
+    const double*  pm_info;  // [info_planes][E]
+    const int*     chunk_pose;  // [n_chunks] pose slot
+    const int*     chunk_begin; // [n_chunks+1]
+    const int*     pose_chunk_ptr; // [Pn+1] chunks of pose slot s
+
+    // pose-only / landmark-only edges (rank 0 holds se3 + accel; lmlm lives with its free landmark)
+    const int*    se3_i;    // [n_se3] pose slots
+    const int*    se3_j;
+    const double* se3_Z;    // [n_se3][12]
+    const double* se3_info; // [n_se3][21]
+    const uint8_t* se3_robust;
+    const int*    acc_pose; // [n_accel]
+    const double* acc_a;    // [n_accel][3]  (already rotated by the offset: R_off a)
+    const double* acc_info; // [n_accel][6]
+    const int*    ll_free;  // [n_lmlm] local landmark that is optimised
+    const double* ll_ref;   // [n_lmlm][3]  position of the fixed partner
+    const double* ll_z;     // [n_lmlm][3]  measurement, sign-adjusted so that e = p_free - ref - z
+    const double* ll_info;  // [n_lmlm][6]
+    const uint8_t* ll_robust;
+    const int*    lm_ll_ptr; // [Ll+1] lmlm edges per landmark (sorted by ll_free)
+    // per pose: references into the aux-edge outputs that add to its diagonal block / rhs
+    const int*    pose_aux_ptr; // [Pn+1]
+    const int*    pose_aux_ref; // se3 edge k as (k<<2)|0 (role i) or |1 (role j); accel edge k as (k<<2)|2
+
+    // linearisation outputs
+    double* W;        // [18][E]  H_pl per edge = J_p' (rho1 Omega) J_l, row-major 6x3 -> plane 3*a+c
+    double* Hll;      // [6][Ll]  upper triangle of H_ll
+    double* bl;       // [3][Ll]
+    double* Hinv;     // [6][Ll]  (H_ll + lambda I)^-1, per trial
+    double* chunk_out;// [n_chunks][27]  21 (upper of 6x6) + 6
+    double* se3_out;  // [n_se3][120]  Hii(36) Hjj(36) Hij(36) bi(6) bj(6)
+    double* acc_out;  // [n_accel][42] H(36) b(6)
+    // lin_buf (one all-reduce per linearisation): Hpp[Pf][21] | bp[Pf][6] | chi_robust chi_plain | maxdiag[n_ranks]
+    double* lin_buf;
+    double* Hpp;      // = lin_buf
+    double* bp;       // = lin_buf + 21*Pf
+    double* lin_scal; // = lin_buf + 27*Pf : [0] robust chi2, [1] plain chi2, [2..2+n_ranks) max diag of H_ll per rank
+    int     lin_count;
+    double* block_part; // [max(n_lm_blocks, n_chunks)][4] per-workgroup partial sums
+
+    // reduced system
+    int TS, NT;            // tile edge, tiles per side
+    int n_tiles;           // stored tiles
+    const int* tile_map;   // [NT][NT] lower triangle -> tile id or -1
+    double* S;             // red_buf: [n_tiles][TS*TS] | g[NT*TS]   (one all-reduce per trial)
+    double* g;             // = S + n_tiles*TS*TS
+    int     red_count;
+    double* Linv;          // [NT][TS*TS] inverses of the diagonal Cholesky factors
+    double* dx;            // [NT*TS] solution (pose increments)
+    int*    chol_status;   // [1] 0 ok, k+1: pivot failure in tile column k
+
+    // Schur jobs
+    int n_items, n_jobs;
+    const int* it_lm;      // [n_items]
+    const int* it_a0;      // first lm-major edge of the row segment
+    const int* it_na;
+    const int* it_b0;      // first edge of the column segment (== it_a0 for diagonal tiles)
+    const int* it_nb;
+    const int* job_item0;  // [n_jobs+1]
+    const int* job_pair0;  // [n_items+1] prefix of pair counts (global)
+    const int* job_tile;   // [n_jobs] tile id
+    const int* job_ti;     // [n_jobs] tile row (for diagonal tiles also the g block)
+    const int* job_tj;     // [n_jobs]
+    double* slab;          // [n_jobs][TS*TS]
+    double* gslab;         // [n_jobs][TS]
+    // assembly lists per stored tile
+    const int* tile_job_ptr;  // [n_tiles+1]
+    const int* tile_jobs;     // job ids in fixed order
+    const int* tile_ti;       // [n_tiles]
+    const int* tile_tj;
+    const int* tile_aux_ptr;  // [n_tiles+1]
+    const int* tile_aux_ref;  // (se3 edge << 1) | transposed
+    int add_pose_terms;       // rank 0 adds Hpp / bp / odometry blocks
+
+    // LM scalars on the device
+    double* scal;   // [8]: 0 chi_robust(trial) 1 chi_plain(trial) 2 scale_lm 3 scale_pose 4 spare...
+};
+
+// tile-sparse Cholesky of the reduced system (ba_chol.hip)
+struct CholPlan {
+    int TS = 0, NT = 0;
+    // per tile column k: sub-diagonal tiles and update triples, flattened
+    const int* col_ptr = nullptr;   // [NT+1] into trsm_tile
+    const int* trsm_tile = nullptr; // tile ids (i,k), i>k
+    const int* trsm_row = nullptr;  // tile row i
+    const int* upd_ptr = nullptr;   // [NT+1] into upd_*
+    const int* upd_a = nullptr;     // tile (i,k)
+    const int* upd_b = nullptr;     // tile (j,k)
+    const int* upd_c = nullptr;     // tile (i,j)
+    // host copies of the counts
+    const int* h_col_ptr = nullptr;
+    const int* h_upd_ptr = nullptr;
+    const int* h_diag_tile = nullptr; // tile id of (k,k)
+    const int* diag_tile = nullptr;   // device copy
+    // row lists for the triangular solves
+    const int* row_ptr = nullptr;     // [NT+1] tiles (k,j), j<k  (device)
+    const int* row_tile = nullptr;
+    const int* row_col = nullptr;
+    const int* colb_ptr = nullptr;    // [NT+1] tiles (i,k), i>k  (device)  == col_ptr/trsm_tile/trsm_row
+};
+
+} // namespace svi

@@ -1,0 +1,1204 @@
+// ba_host.cpp — C ABI of the bundle adjustment (include/svi_hot.h): graph construction with the
+// reference's rules, structure analysis, and the Levenberg-Marquardt driver.
+//
+// Reference behaviour mirrored here
+//   Cg2oOptimizer::_setAndgetPose                 src/optimization/Cg2oOptimizer.cpp:1229-1290
+//   Cg2oOptimizer::_getEdgeLinearAcceleration     :982-997
+//   Cg2oOptimizer::_setLandmarkMeasurementsWORLD  :1383-1466  (+ factories :999-1073)
+//   Cg2oOptimizer::_optimizeUnLimited             :954-980
+//   Cg2oOptimizer::_applyOptimizationToLandmarks  :1468-1512 (pruning rule)
+//   g2o OptimizationAlgorithmLevenberg::solve / SparseOptimizer::optimize  
+// The linear algebra is NOT g2o's: landmarks are eliminated per 3x3 block (Schur complement) and
+// the reduced camera system is factorised tile-sparse on the GPU; the increment is the same up to
+// round-off (SURVEY.md "Quick facts").
+#include "ba_host.h"
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <numeric>
+
+#include "ba_math.h"
+
+namespace svi {
+// launchers defined in ba_kernels.hip / ba_chol.hip
+void ba_linearize_lm(const BaDev& d, int cur, void* st);
+void ba_linearize_pose(const BaDev& d, int cur, void* st);
+void ba_linearize_aux(const BaDev& d, int cur, int rank, void* st);
+void ba_chi2_aux(const BaDev& d, int which, int rank, void* st);
+void ba_pose_finalize(const BaDev& d, const int* red_slot, int rank, int n_ranks, void* st);
+void ba_lin_post(const BaDev& d, int n_ranks, void* st);
+void ba_invert_landmarks(const BaDev& d, double lambda, void* st);
+void ba_schur(const BaDev& d, void* st);
+void ba_assemble(const BaDev& d, void* st);
+void ba_update_poses(const BaDev& d, int cur, double lambda, void* st);
+void ba_backsub_chi2(const BaDev& d, int cur, double lambda, void* st);
+void ba_chi2_only(const BaDev& d, int which, void* st);
+void ba_reduce_trial_scalars(const BaDev& d, void* st);
+void ba_debug_jacobians(const BaDev& d, int cur, const int* e_orig, double* err, double* Jp, double* Jl, void* st);
+void ba_configure_kernels(int TS);
+void chol_factor_solve(const CholPlan& p, double* tiles, double* Linv, const double* g, double* x, double lambda, int n,
+                       int* status, void* st);
+
+void PhaseTimer::begin(int phase, hipStream_t s)
+{
+    if (!on) return;
+    if (used == pool.size()) {
+        Rec r{phase, nullptr, nullptr};
+        (void)hipEventCreate(&r.a);
+        (void)hipEventCreate(&r.b);
+        pool.push_back(r);
+    }
+    pool[used].phase = phase;
+    (void)hipEventRecord(pool[used].a, s);
+}
+void PhaseTimer::end(hipStream_t s)
+{
+    if (!on) return;
+    (void)hipEventRecord(pool[used].b, s);
+    ++used;
+}
+void PhaseTimer::collect()
+{
+    for (size_t i = 0; i < used; ++i) {
+        float t = 0.f;
+        if (hipEventElapsedTime(&t, pool[i].a, pool[i].b) == hipSuccess) { ms[pool[i].phase] += t; calls[pool[i].phase]++; }
+    }
+    used = 0;
+}
+void PhaseTimer::release()
+{
+    for (auto& r : pool) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    pool.clear();
+    used = 0;
+}
+} // namespace svi
+
+using namespace svi;
+
+namespace {
+
+const double kIdentity12[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+
+void free_device(svi_ba* ba)
+{
+    for (void* p : ba->allocs) (void)hipFree(p);
+    ba->allocs.clear();
+    if (ba->h_scal) { (void)hipHostFree(ba->h_scal); ba->h_scal = nullptr; }
+    if (ba->h_status) { (void)hipHostFree(ba->h_status); ba->h_status = nullptr; }
+    ba->initialized = false;
+    ba->d = BaDev{};
+    ba->plan = CholPlan{};
+}
+
+template <class T> int dev_upload(svi_ba* ba, const std::vector<T>& h, const T** out, size_t min_elems = 1)
+{
+    const size_t n = std::max(h.size(), min_elems);
+    void* p = nullptr;
+    SVI_HIP(hipMalloc(&p, n * sizeof(T)));
+    ba->allocs.push_back(p);
+    if (!h.empty()) SVI_HIP(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ba->stream));
+    *out = static_cast<const T*>(p);
+    return SVI_OK;
+}
+template <class T> int dev_alloc(svi_ba* ba, size_t n, T** out, bool zero = true)
+{
+    void* p = nullptr;
+    n = std::max<size_t>(n, 1);
+    SVI_HIP(hipMalloc(&p, n * sizeof(T)));
+    ba->allocs.push_back(p);
+    if (zero) SVI_HIP(hipMemsetAsync(p, 0, n * sizeof(T), ba->stream));
+    *out = static_cast<T*>(p);
+    return SVI_OK;
+}
+
+#define SVI_TRY(x) do { int rc_ = (x); if (rc_ != SVI_OK) return rc_; } while (0)
+
+int allreduce(svi_ba* ba, double* buf, size_t count)
+{
+    if (ba->opt.n_ranks <= 1) return SVI_OK;
+    if (!ba->ar) return fail(SVI_ERR_STATE, "n_ranks > 1 but no all-reduce hook set (svi_ba_set_allreduce)");
+    ba->timer.begin(SVI_PH_ALLREDUCE, ba->stream);
+    const int rc = ba->ar(ba->ar_user, buf, count, ba->stream);
+    ba->timer.end(ba->stream);
+    if (rc != 0) return fail(SVI_ERR_COMM, "all-reduce hook returned %d", rc);
+    return SVI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// structure analysis (g2o initializeOptimization + buildStructure equivalent)
+// ---------------------------------------------------------------------------------------------
+int build_structure(svi_ba* ba)
+{
+    BaDev& d = ba->d;
+    const svi_ba_options& o = ba->opt;
+    d.fx = o.fx; d.fy = o.fy; d.cx = o.cx; d.cy = o.cy; d.cauchy_delta = o.cauchy_delta;
+    const int Pn = (int)ba->poses.size();
+    const int Ltot = (int)ba->lms.size();
+
+    // ---- vertex order: ascending id (g2o index mapping) ----
+    ba->pose_order.resize(Pn);
+    std::iota(ba->pose_order.begin(), ba->pose_order.end(), 0);
+    std::sort(ba->pose_order.begin(), ba->pose_order.end(), [&](int a, int b) { return ba->poses[a].id < ba->poses[b].id; });
+    std::vector<int> pose_slot(Pn), pose_red(Pn), red_slot;
+    for (int s = 0; s < Pn; ++s) pose_slot[ba->pose_order[s]] = s;
+    for (int s = 0; s < Pn; ++s) {
+        if (ba->poses[ba->pose_order[s]].fixed) pose_red[s] = -1;
+        else { pose_red[s] = (int)red_slot.size(); red_slot.push_back(s); }
+    }
+    const int Pf = (int)red_slot.size();
+    ba->lm_order.resize(Ltot);
+    std::iota(ba->lm_order.begin(), ba->lm_order.end(), 0);
+    std::sort(ba->lm_order.begin(), ba->lm_order.end(), [&](int a, int b) { return ba->lms[a].id < ba->lms[b].id; });
+    std::vector<int> lm_slot(Ltot);
+    for (int s = 0; s < Ltot; ++s) lm_slot[ba->lm_order[s]] = s;
+
+    // ---- landmark sharding: contiguous slot ranges balanced by projection-edge count ----
+    std::vector<int64_t> deg(Ltot + 1, 0);
+    for (const HProj& e : ba->proj) deg[lm_slot[e.lm] + 1]++;
+    for (int s = 0; s < Ltot; ++s) deg[s + 1] += deg[s];
+    const int64_t Etot = (int64_t)ba->proj.size();
+    ba->E_total = Etot;
+    auto bound = [&](int r) -> int {
+        if (r <= 0) return 0;
+        if (r >= o.n_ranks) return Ltot;
+        const int64_t want = Etot * r / o.n_ranks;
+        int s = (int)(std::lower_bound(deg.begin(), deg.end(), want) - deg.begin());
+        return std::min(std::max(s, 0), Ltot);
+    };
+    ba->L0 = bound(o.rank);
+    ba->L1 = bound(o.rank + 1);
+    const int L0 = ba->L0, Ll = ba->L1 - ba->L0;
+
+    // ---- local projection edges, lm-major: (landmark, reduced pose [fixed first], slot) ----
+    std::vector<int> loc;
+    loc.reserve(ba->proj.size());
+    for (int i = 0; i < (int)ba->proj.size(); ++i) {
+        const int s = lm_slot[ba->proj[i].lm];
+        if (s >= L0 && s < ba->L1) loc.push_back(i);
+    }
+    const int E = (int)loc.size();
+    std::sort(loc.begin(), loc.end(), [&](int a, int b) {
+        const HProj &x = ba->proj[a], &y = ba->proj[b];
+        const int lx = lm_slot[x.lm], ly = lm_slot[y.lm];
+        if (lx != ly) return lx < ly;
+        const int rx = pose_red[pose_slot[x.pose]], ry = pose_red[pose_slot[y.pose]];
+        if (rx != ry) return rx < ry;
+        if (pose_slot[x.pose] != pose_slot[y.pose]) return pose_slot[x.pose] < pose_slot[y.pose];
+        return a < b;
+    });
+    bool diag_info = true;
+    for (const HProj& e : ba->proj) if (e.info[1] != 0.0 || e.info[2] != 0.0 || e.info[4] != 0.0) { diag_info = false; break; }
+    const int planes = diag_info ? 3 : 6;
+    static const int kDiagIdx[3] = {0, 3, 5};
+    std::vector<int> e_pose(E), e_lm(E), e_orig(E), lm_ptr(Ll + 1, 0);
+    std::vector<uint8_t> e_flags(E);
+    std::vector<double> e_z((size_t)3 * E), e_info((size_t)planes * E);
+    for (int k = 0; k < E; ++k) {
+        const HProj& e = ba->proj[loc[k]];
+        e_pose[k] = pose_slot[e.pose];
+        e_lm[k] = lm_slot[e.lm] - L0;
+        e_orig[k] = loc[k];
+        e_flags[k] = (uint8_t)((e.type & 3) | (e.robust ? kFlagRobust : 0));
+        for (int c = 0; c < 3; ++c) e_z[(size_t)c * E + k] = e.z[c];
+        for (int c = 0; c < planes; ++c) e_info[(size_t)c * E + k] = diag_info ? e.info[kDiagIdx[c]] : e.info[c];
+        lm_ptr[e_lm[k] + 1]++;
+    }
+    for (int l = 0; l < Ll; ++l) {
+        if (lm_ptr[l + 1] > kLmBlockEdges)
+            return fail(SVI_ERR_UNSUPPORTED, "landmark %lld has %d projection edges (limit %d)",
+                        (long long)ba->lms[ba->lm_order[L0 + l]].id, lm_ptr[l + 1], kLmBlockEdges);
+        lm_ptr[l + 1] += lm_ptr[l];
+    }
+    std::vector<int> lb_lm(1, 0);
+    for (int l = 0; l < Ll;) {
+        int l2 = l, edges = 0;
+        while (l2 < Ll && l2 - l < kLmBlockEdges && edges + (lm_ptr[l2 + 1] - lm_ptr[l2]) <= kLmBlockEdges) { edges += lm_ptr[l2 + 1] - lm_ptr[l2]; ++l2; }
+        lb_lm.push_back(l2);
+        l = l2;
+    }
+    const int n_lm_blocks = (int)lb_lm.size() - 1;
+    std::vector<uint8_t> lm_fixed(Ll);
+    for (int l = 0; l < Ll; ++l) lm_fixed[l] = (uint8_t)(ba->lms[ba->lm_order[L0 + l]].fixed ? 1 : 0);
+
+    // ---- pose-major copy: free poses only, (slot, landmark) ----
+    std::vector<int> pm;
+    pm.reserve(E);
+    for (int k = 0; k < E; ++k) if (pose_red[e_pose[k]] >= 0) pm.push_back(k);
+    std::stable_sort(pm.begin(), pm.end(), [&](int a, int b) { return e_pose[a] < e_pose[b]; });
+    const int Epm = (int)pm.size();
+    std::vector<int> pm_lm(Epm), chunk_pose, chunk_begin, pose_chunk_ptr(Pn + 1, 0);
+    std::vector<uint8_t> pm_flags(Epm);
+    // pose-major planes use the same plane stride E as the lm-major arrays (the kernels share load_edge)
+    std::vector<double> pm_z((size_t)3 * E), pm_info((size_t)planes * E);
+    for (int k = 0; k < Epm; ++k) {
+        const int src = pm[k];
+        pm_lm[k] = e_lm[src];
+        pm_flags[k] = e_flags[src];
+        for (int c = 0; c < 3; ++c) pm_z[(size_t)c * E + k] = e_z[(size_t)c * E + src];
+        for (int c = 0; c < planes; ++c) pm_info[(size_t)c * E + k] = e_info[(size_t)c * E + src];
+    }
+    {
+        int k = 0;
+        for (int s = 0; s < Pn; ++s) {
+            pose_chunk_ptr[s] = (int)chunk_pose.size();
+            int k2 = k;
+            while (k2 < Epm && e_pose[pm[k2]] == s) ++k2;
+            for (int b = k; b < k2; b += kPoseChunk) { chunk_pose.push_back(s); chunk_begin.push_back(b); }
+            k = k2;
+        }
+        pose_chunk_ptr[Pn] = (int)chunk_pose.size();
+        chunk_begin.push_back(Epm);
+    }
+    const int n_chunks = (int)chunk_pose.size();
+    // chunks are contiguous: the next chunk (same or next pose) starts exactly where this one ends,
+    // so chunk_begin[c+1] is the end of chunk c
+
+    // ---- pose-only / landmark-only edges ----
+    std::vector<int> se3_i, se3_j, acc_pose, ll_free;
+    std::vector<double> se3_Z, se3_info, acc_a, acc_info, ll_ref, ll_z, ll_info;
+    std::vector<uint8_t> se3_robust, ll_robust;
+    std::vector<std::vector<int>> pose_aux(Pn);
+    if (o.rank == 0) {
+        for (const HSe3& e : ba->se3) {
+            const int k = (int)se3_i.size();
+            se3_i.push_back(pose_slot[e.i]); se3_j.push_back(pose_slot[e.j]);
+            se3_Z.insert(se3_Z.end(), e.Z, e.Z + 12);
+            se3_info.insert(se3_info.end(), e.info, e.info + 21);
+            se3_robust.push_back((uint8_t)(e.robust ? 1 : 0));
+            pose_aux[pose_slot[e.i]].push_back((k << 2) | 0);
+            pose_aux[pose_slot[e.j]].push_back((k << 2) | 1);
+        }
+        for (const HAcc& e : ba->acc) {
+            const int k = (int)acc_pose.size();
+            acc_pose.push_back(pose_slot[e.pose]);
+            for (int r = 0; r < 3; ++r) acc_a.push_back(e.off[3 * r] * e.a[0] + e.off[3 * r + 1] * e.a[1] + e.off[3 * r + 2] * e.a[2]);
+            acc_info.insert(acc_info.end(), e.info, e.info + 6);
+            pose_aux[pose_slot[e.pose]].push_back((k << 2) | 2);
+        }
+    }
+    std::vector<int> pose_aux_ptr(Pn + 1, 0), pose_aux_ref;
+    for (int s = 0; s < Pn; ++s) {
+        pose_aux_ptr[s] = (int)pose_aux_ref.size();
+        pose_aux_ref.insert(pose_aux_ref.end(), pose_aux[s].begin(), pose_aux[s].end());
+    }
+    pose_aux_ptr[Pn] = (int)pose_aux_ref.size();
+    {
+        struct LL { int free_l; double ref[3], z[3], info[6]; uint8_t robust; };
+        std::vector<LL> v;
+        for (const HLL& e : ba->lmlm) {
+            const HLm &li = ba->lms[e.i], &lj = ba->lms[e.j];
+            if (!li.fixed && !lj.fixed)
+                return fail(SVI_ERR_UNSUPPORTED, "landmark-landmark edge %lld-%lld with two free ends (the reference fixes one, Cg2oOptimizer.cpp:445)",
+                            (long long)li.id, (long long)lj.id);
+            if (li.fixed && lj.fixed) continue;
+            LL x{};
+            const bool free_is_j = li.fixed != 0;
+            const HLm& fr = free_is_j ? lj : li;
+            const HLm& fx = free_is_j ? li : lj;
+            const int s = lm_slot[free_is_j ? e.j : e.i];
+            if (s < L0 || s >= ba->L1) continue;
+            x.free_l = s - L0;
+            (void)fr;
+            for (int c = 0; c < 3; ++c) { x.ref[c] = fx.p[c]; x.z[c] = free_is_j ? e.z[c] : -e.z[c]; }
+            memcpy(x.info, e.info, sizeof(x.info));
+            x.robust = (uint8_t)(e.robust ? 1 : 0);
+            v.push_back(x);
+        }
+        std::stable_sort(v.begin(), v.end(), [](const LL& a, const LL& b) { return a.free_l < b.free_l; });
+        for (const LL& x : v) {
+            ll_free.push_back(x.free_l);
+            ll_ref.insert(ll_ref.end(), x.ref, x.ref + 3);
+            ll_z.insert(ll_z.end(), x.z, x.z + 3);
+            ll_info.insert(ll_info.end(), x.info, x.info + 6);
+            ll_robust.push_back(x.robust);
+        }
+    }
+    std::vector<int> lm_ll_ptr(Ll + 1, 0);
+    for (int f : ll_free) lm_ll_ptr[f + 1]++;
+    for (int l = 0; l < Ll; ++l) lm_ll_ptr[l + 1] += lm_ll_ptr[l];
+
+    // ---- reduced system tiling (identical on every rank: derived from the GLOBAL graph) ----
+    int TS = o.chol_tile > 0 ? o.chol_tile : 96;
+    if (TS % 48 != 0 || TS > kMaxTile) return fail(SVI_ERR_INVALID, "chol_tile must be 48 or 96");
+    const int PB = TS / 6;
+    const int n = 6 * Pf;
+    const int NT = (n + TS - 1) / TS;
+    std::vector<uint8_t> nz((size_t)NT * NT, 0);
+    for (int t = 0; t < NT; ++t) nz[(size_t)t * NT + t] = 1;
+    {
+        // chunks touched by every landmark of the global graph
+        std::vector<std::vector<int>> lm_chunks(Ltot);
+        for (const HProj& e : ba->proj) {
+            const int r = pose_red[pose_slot[e.pose]];
+            if (r >= 0 && !ba->lms[e.lm].fixed) lm_chunks[e.lm].push_back(r / PB);
+        }
+        for (auto& v : lm_chunks) {
+            std::sort(v.begin(), v.end());
+            v.erase(std::unique(v.begin(), v.end()), v.end());
+            for (size_t a = 0; a < v.size(); ++a)
+                for (size_t b = 0; b <= a; ++b) nz[(size_t)v[a] * NT + v[b]] = 1;
+        }
+        for (const HSe3& e : ba->se3) {
+            const int ri = pose_red[pose_slot[e.i]], rj = pose_red[pose_slot[e.j]];
+            if (ri >= 0 && rj >= 0) { const int a = std::max(ri, rj) / PB, b = std::min(ri, rj) / PB; nz[(size_t)a * NT + b] = 1; }
+        }
+    }
+    // symbolic fill, right-looking over tile columns
+    std::vector<int> h_col_ptr(NT + 1, 0), h_upd_ptr(NT + 1, 0);
+    std::vector<std::pair<int, int>> col_rows;            // (k, i)
+    std::vector<int> upd_i, upd_j, upd_k;
+    for (int k = 0; k < NT; ++k) {
+        std::vector<int> rows;
+        for (int i = k + 1; i < NT; ++i) if (nz[(size_t)i * NT + k]) rows.push_back(i);
+        h_col_ptr[k] = (int)col_rows.size();
+        h_upd_ptr[k] = (int)upd_i.size();
+        for (int i : rows) col_rows.push_back({k, i});
+        for (size_t a = 0; a < rows.size(); ++a)
+            for (size_t b = 0; b <= a; ++b) {
+                nz[(size_t)rows[a] * NT + rows[b]] = 1;
+                upd_i.push_back(rows[a]); upd_j.push_back(rows[b]); upd_k.push_back(k);
+            }
+    }
+    h_col_ptr[NT] = (int)col_rows.size();
+    h_upd_ptr[NT] = (int)upd_i.size();
+    std::vector<int> tile_map((size_t)NT * NT, -1), tile_ti, tile_tj;
+    for (int j = 0; j < NT; ++j)
+        for (int i = j; i < NT; ++i)
+            if (nz[(size_t)i * NT + j]) { tile_map[(size_t)i * NT + j] = (int)tile_ti.size(); tile_ti.push_back(i); tile_tj.push_back(j); }
+    const int n_tiles = (int)tile_ti.size();
+    std::vector<int> trsm_tile, trsm_row, upd_a, upd_b, upd_c, diag_tile(NT), row_ptr(NT + 1, 0), row_tile, row_col;
+    for (auto& kr : col_rows) { trsm_tile.push_back(tile_map[(size_t)kr.second * NT + kr.first]); trsm_row.push_back(kr.second); }
+    for (size_t u = 0; u < upd_i.size(); ++u) {
+        upd_a.push_back(tile_map[(size_t)upd_i[u] * NT + upd_k[u]]);
+        upd_b.push_back(tile_map[(size_t)upd_j[u] * NT + upd_k[u]]);
+        upd_c.push_back(tile_map[(size_t)upd_i[u] * NT + upd_j[u]]);
+    }
+    double chol_flops = 0.0;
+    for (int k = 0; k < NT; ++k) {
+        diag_tile[k] = tile_map[(size_t)k * NT + k];
+        row_ptr[k] = (int)row_tile.size();
+        for (int j = 0; j < k; ++j) if (tile_map[(size_t)k * NT + j] >= 0) { row_tile.push_back(tile_map[(size_t)k * NT + j]); row_col.push_back(j); }
+        const double t3 = (double)TS * TS * TS;
+        chol_flops += t3 / 3.0 + t3 * (h_col_ptr[k + 1] - h_col_ptr[k]) + 2.0 * t3 * (h_upd_ptr[k + 1] - h_upd_ptr[k]);
+    }
+    row_ptr[NT] = (int)row_tile.size();
+
+    // ---- Schur items (local landmarks) grouped by tile into jobs ----
+    struct Item { int tile, lm, a0, na, b0, nb; };
+    std::vector<Item> items;
+    for (int l = 0; l < Ll; ++l) {
+        if (lm_fixed[l]) continue;
+        int a = lm_ptr[l];
+        const int end = lm_ptr[l + 1];
+        while (a < end && pose_red[e_pose[a]] < 0) ++a; // edges to fixed poses come first
+        std::vector<std::pair<int, int>> seg; // (begin, count), one per pose chunk
+        std::vector<int> seg_chunk;
+        while (a < end) {
+            const int c = pose_red[e_pose[a]] / PB;
+            int b = a;
+            while (b < end && pose_red[e_pose[b]] / PB == c) ++b;
+            seg.push_back({a, b - a});
+            seg_chunk.push_back(c);
+            a = b;
+        }
+        for (size_t x = 0; x < seg.size(); ++x)
+            for (size_t y = 0; y <= x; ++y)
+                items.push_back({tile_map[(size_t)seg_chunk[x] * NT + seg_chunk[y]], l, seg[x].first, seg[x].second, seg[y].first, seg[y].second});
+    }
+    // duplicate (pose, landmark) edges would alias one 6x6 block inside an item; the reference never
+    // creates them (one measurement per landmark per keyframe), reject instead of mis-summing
+    for (int l = 0; l < Ll; ++l)
+        for (int a = lm_ptr[l] + 1; a < lm_ptr[l + 1]; ++a)
+            if (e_pose[a] == e_pose[a - 1])
+                return fail(SVI_ERR_UNSUPPORTED, "two projection edges between pose %lld and landmark %lld",
+                            (long long)ba->poses[ba->pose_order[e_pose[a]]].id, (long long)ba->lms[ba->lm_order[L0 + l]].id);
+    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.tile < b.tile; });
+    const int n_items = (int)items.size();
+    std::vector<int> it_lm(n_items), it_a0(n_items), it_na(n_items), it_b0(n_items), it_nb(n_items), job_pair0(n_items + 1, 0);
+    int64_t total_pairs = 0;
+    for (int i = 0; i < n_items; ++i) {
+        const Item& it = items[i];
+        it_lm[i] = it.lm; it_a0[i] = it.a0; it_na[i] = it.na; it_b0[i] = it.b0; it_nb[i] = it.nb;
+        const bool dg = tile_ti[it.tile] == tile_tj[it.tile];
+        const int64_t np = dg ? (int64_t)it.na * (it.na + 1) / 2 : (int64_t)it.na * it.nb;
+        total_pairs += np;
+        if (total_pairs > 0x7fffffff) return fail(SVI_ERR_UNSUPPORTED, "too many Schur block pairs for 32-bit indexing");
+        job_pair0[i + 1] = (int)total_pairs;
+    }
+    const int64_t target = std::max<int64_t>(2048, total_pairs / 1024);
+    std::vector<int> job_item0(1, 0), job_tile, job_ti, job_tj;
+    for (int i = 0; i < n_items;) {
+        const int tile = items[i].tile;
+        int j = i;
+        const int64_t base = job_pair0[i];
+        while (j < n_items && items[j].tile == tile && (j == i || job_pair0[j + 1] - base <= target)) ++j;
+        job_tile.push_back(tile); job_ti.push_back(tile_ti[tile]); job_tj.push_back(tile_tj[tile]);
+        job_item0.push_back(j);
+        i = j;
+    }
+    const int n_jobs = (int)job_tile.size();
+    std::vector<int> tile_job_ptr(n_tiles + 1, 0), tile_jobs(n_jobs);
+    for (int j = 0; j < n_jobs; ++j) tile_job_ptr[job_tile[j] + 1]++;
+    for (int t = 0; t < n_tiles; ++t) tile_job_ptr[t + 1] += tile_job_ptr[t];
+    {
+        std::vector<int> fill(tile_job_ptr.begin(), tile_job_ptr.end() - 1);
+        for (int j = 0; j < n_jobs; ++j) tile_jobs[fill[job_tile[j]]++] = j;
+    }
+    std::vector<std::vector<int>> taux(n_tiles);
+    for (int k = 0; k < (int)se3_i.size(); ++k) {
+        const int ri = pose_red[se3_i[k]], rj = pose_red[se3_j[k]];
+        if (ri < 0 || rj < 0 || ri == rj) continue;
+        const int tr = ri > rj ? 0 : 1; // row pose = the one with the larger reduced index
+        const int hi = std::max(ri, rj), lo = std::min(ri, rj);
+        taux[tile_map[(size_t)(hi / PB) * NT + lo / PB]].push_back((k << 1) | tr);
+    }
+    std::vector<int> tile_aux_ptr(n_tiles + 1, 0), tile_aux_ref;
+    for (int t = 0; t < n_tiles; ++t) {
+        tile_aux_ptr[t] = (int)tile_aux_ref.size();
+        tile_aux_ref.insert(tile_aux_ref.end(), taux[t].begin(), taux[t].end());
+    }
+    tile_aux_ptr[n_tiles] = (int)tile_aux_ref.size();
+
+    // ---- upload ----
+    d.Pn = Pn; d.Pf = Pf; d.Ll = Ll; d.E = E;
+    d.n_lm_blocks = n_lm_blocks; d.n_chunks = n_chunks;
+    d.n_se3 = (int)se3_i.size(); d.n_accel = (int)acc_pose.size(); d.n_lmlm = (int)ll_free.size();
+    d.info_planes = planes;
+    std::vector<double> hp((size_t)12 * Pn), hl((size_t)3 * Ll);
+    for (int s = 0; s < Pn; ++s) memcpy(&hp[(size_t)12 * s], ba->poses[ba->pose_order[s]].T, 96);
+    for (int l = 0; l < Ll; ++l) memcpy(&hl[(size_t)3 * l], ba->lms[ba->lm_order[L0 + l]].p, 24);
+    for (int b = 0; b < 2; ++b) {
+        const double* p = nullptr;
+        SVI_TRY(dev_upload(ba, hp, &p)); d.pose[b] = const_cast<double*>(p);
+        SVI_TRY(dev_upload(ba, hl, &p)); d.lm[b] = const_cast<double*>(p);
+    }
+    SVI_TRY(dev_upload(ba, pose_red, &d.pose_red));
+    SVI_TRY(dev_upload(ba, lm_fixed, &d.lm_fixed));
+    SVI_TRY(dev_upload(ba, e_pose, &d.e_pose));
+    SVI_TRY(dev_upload(ba, e_lm, &d.e_lm));
+    SVI_TRY(dev_upload(ba, e_flags, &d.e_flags));
+    SVI_TRY(dev_upload(ba, e_z, &d.e_z));
+    SVI_TRY(dev_upload(ba, e_info, &d.e_info));
+    SVI_TRY(dev_upload(ba, lm_ptr, &d.lm_ptr));
+    SVI_TRY(dev_upload(ba, lb_lm, &d.lb_lm));
+    SVI_TRY(dev_upload(ba, pm_lm, &d.pm_lm));
+    SVI_TRY(dev_upload(ba, pm_flags, &d.pm_flags));
+    SVI_TRY(dev_upload(ba, pm_z, &d.pm_z));
+    SVI_TRY(dev_upload(ba, pm_info, &d.pm_info));
+    SVI_TRY(dev_upload(ba, chunk_pose, &d.chunk_pose));
+    SVI_TRY(dev_upload(ba, chunk_begin, &d.chunk_begin));
+    SVI_TRY(dev_upload(ba, pose_chunk_ptr, &d.pose_chunk_ptr));
+    SVI_TRY(dev_upload(ba, se3_i, &d.se3_i));
+    SVI_TRY(dev_upload(ba, se3_j, &d.se3_j));
+    SVI_TRY(dev_upload(ba, se3_Z, &d.se3_Z));
+    SVI_TRY(dev_upload(ba, se3_info, &d.se3_info));
+    SVI_TRY(dev_upload(ba, se3_robust, &d.se3_robust));
+    SVI_TRY(dev_upload(ba, acc_pose, &d.acc_pose));
+    SVI_TRY(dev_upload(ba, acc_a, &d.acc_a));
+    SVI_TRY(dev_upload(ba, acc_info, &d.acc_info));
+    SVI_TRY(dev_upload(ba, ll_free, &d.ll_free));
+    SVI_TRY(dev_upload(ba, ll_ref, &d.ll_ref));
+    SVI_TRY(dev_upload(ba, ll_z, &d.ll_z));
+    SVI_TRY(dev_upload(ba, ll_info, &d.ll_info));
+    SVI_TRY(dev_upload(ba, ll_robust, &d.ll_robust));
+    SVI_TRY(dev_upload(ba, lm_ll_ptr, &d.lm_ll_ptr));
+    SVI_TRY(dev_upload(ba, pose_aux_ptr, &d.pose_aux_ptr));
+    SVI_TRY(dev_upload(ba, pose_aux_ref, &d.pose_aux_ref));
+    {
+        const int* p = nullptr;
+        SVI_TRY(dev_upload(ba, red_slot, &p)); ba->red_slot = const_cast<int*>(p);
+        SVI_TRY(dev_upload(ba, e_orig, &p)); ba->e_orig = const_cast<int*>(p);
+    }
+    SVI_TRY(dev_alloc(ba, (size_t)18 * E, &d.W));
+    SVI_TRY(dev_alloc(ba, (size_t)6 * Ll, &d.Hll));
+    SVI_TRY(dev_alloc(ba, (size_t)3 * Ll, &d.bl));
+    SVI_TRY(dev_alloc(ba, (size_t)6 * Ll, &d.Hinv));
+    SVI_TRY(dev_alloc(ba, (size_t)27 * n_chunks, &d.chunk_out));
+    SVI_TRY(dev_alloc(ba, (size_t)120 * d.n_se3, &d.se3_out));
+    SVI_TRY(dev_alloc(ba, (size_t)42 * d.n_accel, &d.acc_out));
+    d.lin_count = 27 * Pf + 2 + o.n_ranks;
+    SVI_TRY(dev_alloc(ba, (size_t)d.lin_count, &d.lin_buf));
+    d.Hpp = d.lin_buf; d.bp = d.lin_buf + (size_t)21 * Pf; d.lin_scal = d.lin_buf + (size_t)27 * Pf;
+    SVI_TRY(dev_alloc(ba, (size_t)4 * std::max(n_lm_blocks, 1), &d.block_part));
+    d.TS = TS; d.NT = NT; d.n_tiles = n_tiles;
+    SVI_TRY(dev_upload(ba, tile_map, &d.tile_map));
+    d.red_count = n_tiles * TS * TS + NT * TS;
+    SVI_TRY(dev_alloc(ba, (size_t)d.red_count, &d.S));
+    d.g = d.S + (size_t)n_tiles * TS * TS;
+    SVI_TRY(dev_alloc(ba, (size_t)NT * TS * TS, &d.Linv));
+    SVI_TRY(dev_alloc(ba, (size_t)NT * TS, &d.dx));
+    SVI_TRY(dev_alloc(ba, 1, &d.chol_status));
+    d.n_items = n_items; d.n_jobs = n_jobs;
+    SVI_TRY(dev_upload(ba, it_lm, &d.it_lm));
+    SVI_TRY(dev_upload(ba, it_a0, &d.it_a0));
+    SVI_TRY(dev_upload(ba, it_na, &d.it_na));
+    SVI_TRY(dev_upload(ba, it_b0, &d.it_b0));
+    SVI_TRY(dev_upload(ba, it_nb, &d.it_nb));
+    SVI_TRY(dev_upload(ba, job_item0, &d.job_item0));
+    SVI_TRY(dev_upload(ba, job_pair0, &d.job_pair0));
+    SVI_TRY(dev_upload(ba, job_tile, &d.job_tile));
+    SVI_TRY(dev_upload(ba, job_ti, &d.job_ti));
+    SVI_TRY(dev_upload(ba, job_tj, &d.job_tj));
+    SVI_TRY(dev_alloc(ba, (size_t)n_jobs * TS * TS, &d.slab, false));
+    SVI_TRY(dev_alloc(ba, (size_t)n_jobs * TS, &d.gslab, false));
+    SVI_TRY(dev_upload(ba, tile_job_ptr, &d.tile_job_ptr));
+    SVI_TRY(dev_upload(ba, tile_jobs, &d.tile_jobs));
+    SVI_TRY(dev_upload(ba, tile_ti, &d.tile_ti));
+    SVI_TRY(dev_upload(ba, tile_tj, &d.tile_tj));
+    SVI_TRY(dev_upload(ba, tile_aux_ptr, &d.tile_aux_ptr));
+    SVI_TRY(dev_upload(ba, tile_aux_ref, &d.tile_aux_ref));
+    d.add_pose_terms = (o.rank == 0) ? 1 : 0;
+    SVI_TRY(dev_alloc(ba, 16, &d.scal));
+    if (o.n_ranks > 1) SVI_TRY(dev_alloc(ba, (size_t)3 * Ltot, &ba->lm_all));
+
+    CholPlan& p = ba->plan;
+    p.TS = TS; p.NT = NT;
+    ba->h_col_ptr = h_col_ptr; ba->h_upd_ptr = h_upd_ptr; ba->h_diag_tile = diag_tile;
+    p.h_col_ptr = ba->h_col_ptr.data(); p.h_upd_ptr = ba->h_upd_ptr.data(); p.h_diag_tile = ba->h_diag_tile.data();
+    SVI_TRY(dev_upload(ba, h_col_ptr, &p.col_ptr));
+    SVI_TRY(dev_upload(ba, trsm_tile, &p.trsm_tile));
+    SVI_TRY(dev_upload(ba, trsm_row, &p.trsm_row));
+    SVI_TRY(dev_upload(ba, h_upd_ptr, &p.upd_ptr));
+    SVI_TRY(dev_upload(ba, upd_a, &p.upd_a));
+    SVI_TRY(dev_upload(ba, upd_b, &p.upd_b));
+    SVI_TRY(dev_upload(ba, upd_c, &p.upd_c));
+    SVI_TRY(dev_upload(ba, diag_tile, &p.diag_tile));
+    SVI_TRY(dev_upload(ba, row_ptr, &p.row_ptr));
+    SVI_TRY(dev_upload(ba, row_tile, &p.row_tile));
+    SVI_TRY(dev_upload(ba, row_col, &p.row_col));
+
+    SVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&ba->h_scal), 16 * sizeof(double)));
+    SVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&ba->h_status), sizeof(int) * 4));
+    ba_configure_kernels(TS);
+    SVI_HIP(hipStreamSynchronize(ba->stream));
+
+    svi_ba_stats& st = ba->stats;
+    const uint64_t it0 = st.lm_iterations, tr0 = st.lm_trials, cf0 = st.chol_failures;
+    st = svi_ba_stats{};
+    st.lm_iterations = it0; st.lm_trials = tr0; st.chol_failures = cf0;
+    st.n_poses = Pn; st.n_poses_free = Pf; st.n_landmarks = Ltot; st.n_landmarks_local = Ll;
+    st.n_edges_proj = Etot; st.n_edges_proj_local = E;
+    st.n_edges_se3 = (int64_t)ba->se3.size(); st.n_edges_accel = (int64_t)ba->acc.size(); st.n_edges_lmlm = (int64_t)ba->lmlm.size();
+    st.n_schur_tiles = n_jobs; st.n_window_blocks = total_pairs;
+    st.chol_n = n; st.chol_tile = TS; st.chol_tiles_nnz = n_tiles;
+    st.reduce_doubles = d.red_count;
+    st.chol_flops = chol_flops;
+    return SVI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// LM pieces
+// ---------------------------------------------------------------------------------------------
+int read_scalars(svi_ba* ba, int n)
+{
+    SVI_HIP(hipMemcpyAsync(ba->h_scal, ba->d.scal, sizeof(double) * n, hipMemcpyDeviceToHost, ba->stream));
+    SVI_HIP(hipMemcpyAsync(ba->h_status, ba->d.chol_status, sizeof(int), hipMemcpyDeviceToHost, ba->stream));
+    SVI_HIP(hipStreamSynchronize(ba->stream));
+    ba->timer.collect();
+    return SVI_OK;
+}
+
+// computeActiveErrors + buildSystem at state `cur`; leaves chi2 (robust, plain) and max|H_jj| in h_scal[0,1,5]
+int linearize(svi_ba* ba)
+{
+    BaDev& d = ba->d;
+    hipStream_t s = ba->stream;
+    PhaseTimer& t = ba->timer;
+    t.begin(SVI_PH_LINEARIZE_LM, s);   ba_linearize_lm(d, ba->cur, s);   t.end(s);
+    t.begin(SVI_PH_LINEARIZE_POSE, s); ba_linearize_pose(d, ba->cur, s); t.end(s);
+    t.begin(SVI_PH_POSE_EDGES, s);
+    ba_linearize_aux(d, ba->cur, ba->opt.rank, s);
+    ba_pose_finalize(d, ba->red_slot, ba->opt.rank, ba->opt.n_ranks, s);
+    t.end(s);
+    SVI_HIP(hipGetLastError());
+    SVI_TRY(allreduce(ba, d.lin_buf, (size_t)d.lin_count));
+    ba_lin_post(d, ba->opt.n_ranks, s);
+    SVI_HIP(hipGetLastError());
+    return read_scalars(ba, 8);
+}
+
+// one trial: solve (H + lambda I) dx = b through the Schur complement, apply, evaluate.
+// results: h_scal[0] robust chi2, [1] plain chi2, [2]+[3] step scale; *failed
+int trial(svi_ba* ba, double lambda, bool* failed)
+{
+    BaDev& d = ba->d;
+    hipStream_t s = ba->stream;
+    PhaseTimer& t = ba->timer;
+    SVI_HIP(hipMemsetAsync(d.chol_status, 0, sizeof(int), s));
+    t.begin(SVI_PH_SCHUR, s);
+    ba_invert_landmarks(d, lambda, s);
+    ba_schur(d, s);
+    t.end(s);
+    t.begin(SVI_PH_ASSEMBLE, s); ba_assemble(d, s); t.end(s);
+    SVI_HIP(hipGetLastError());
+    SVI_TRY(allreduce(ba, d.S, (size_t)d.red_count));
+    t.begin(SVI_PH_CHOLESKY, s);
+    if (d.NT > 0) chol_factor_solve(ba->plan, d.S, d.Linv, d.g, d.dx, lambda, 6 * d.Pf, d.chol_status, s);
+    t.end(s);
+    t.begin(SVI_PH_BACKSUB_UPDATE, s);
+    ba_update_poses(d, ba->cur, lambda, s);
+    ba_backsub_chi2(d, ba->cur, lambda, s);
+    t.end(s);
+    t.begin(SVI_PH_CHI2, s);
+    ba_chi2_aux(d, ba->cur ^ 1, ba->opt.rank, s);
+    ba_reduce_trial_scalars(d, s);
+    t.end(s);
+    SVI_HIP(hipGetLastError());
+    SVI_TRY(allreduce(ba, d.scal, 3));
+    SVI_TRY(read_scalars(ba, 8));
+    *failed = ba->h_status[0] != 0;
+    return SVI_OK;
+}
+
+// keep the host copy of the estimates in step with the device (the reference reads them back in
+// _applyOptimizationTo*, and the admission rule of later measurements uses them)
+int download_state(svi_ba* ba)
+{
+    BaDev& d = ba->d;
+    std::vector<double> hp((size_t)12 * d.Pn), hl((size_t)3 * std::max(d.Ll, 1));
+    if (d.Pn) SVI_HIP(hipMemcpyAsync(hp.data(), d.pose[ba->cur], sizeof(double) * 12 * d.Pn, hipMemcpyDeviceToHost, ba->stream));
+    const int Ltot = (int)ba->lms.size();
+    if (ba->opt.n_ranks > 1) {
+        SVI_HIP(hipMemsetAsync(ba->lm_all, 0, sizeof(double) * 3 * Ltot, ba->stream));
+        if (d.Ll) SVI_HIP(hipMemcpyAsync(ba->lm_all + (size_t)3 * ba->L0, d.lm[ba->cur], sizeof(double) * 3 * d.Ll, hipMemcpyDeviceToDevice, ba->stream));
+        SVI_TRY(allreduce(ba, ba->lm_all, (size_t)3 * Ltot));
+        hl.resize((size_t)3 * std::max(Ltot, 1));
+        if (Ltot) SVI_HIP(hipMemcpyAsync(hl.data(), ba->lm_all, sizeof(double) * 3 * Ltot, hipMemcpyDeviceToHost, ba->stream));
+        SVI_HIP(hipStreamSynchronize(ba->stream));
+        for (int s = 0; s < Ltot; ++s) memcpy(ba->lms[ba->lm_order[s]].p, &hl[(size_t)3 * s], 24);
+    } else {
+        if (d.Ll) SVI_HIP(hipMemcpyAsync(hl.data(), d.lm[ba->cur], sizeof(double) * 3 * d.Ll, hipMemcpyDeviceToHost, ba->stream));
+        SVI_HIP(hipStreamSynchronize(ba->stream));
+        for (int l = 0; l < d.Ll; ++l) memcpy(ba->lms[ba->lm_order[ba->L0 + l]].p, &hl[(size_t)3 * l], 24);
+    }
+    for (int s = 0; s < d.Pn; ++s) memcpy(ba->poses[ba->pose_order[s]].T, &hp[(size_t)12 * s], 96);
+    ba->timer.collect();
+    return SVI_OK;
+}
+
+int optimize_block(svi_ba* ba, int iterations, int* performed)
+{
+    if (!ba->initialized) return fail(SVI_ERR_STATE, "svi_ba_optimize before svi_ba_initialize");
+    SVI_HIP(hipSetDevice(ba->opt.device));
+    const svi_ba_options& o = ba->opt;
+    int done = 0;
+    for (int it = 0; it < iterations; ++it) {
+        SVI_TRY(linearize(ba));
+        double chi = ba->h_scal[0];
+        ba->last_robust = chi; ba->last_plain = ba->h_scal[1]; ba->have_chi = true;
+        if (it == 0) { ba->lambda = o.lm_tau * ba->h_scal[5]; ba->ni = 2.0; } // computeLambdaInit, per optimize() call
+        double rho = 0.0;
+        int q = 0;
+        bool stop_inf = false;
+        do {
+            bool failed = false;
+            SVI_TRY(trial(ba, ba->lambda, &failed));
+            double temp = ba->h_scal[0];
+            if (failed) { temp = DBL_MAX; ba->stats.chol_failures++; }
+            else { ba->last_robust = ba->h_scal[0]; ba->last_plain = ba->h_scal[1]; }
+            const double scale = ba->h_scal[2] + ba->h_scal[3] + 1e-3;
+            rho = (chi - temp) / scale;
+            if (failed) rho = -1.0; // the step of a failed factorisation is never accepted
+            if (rho > 0 && std::isfinite(temp)) {
+                double alpha = 1.0 - std::pow(2.0 * rho - 1.0, 3);
+                alpha = std::min(alpha, o.lm_good_step_upper);
+                ba->lambda *= std::max(o.lm_good_step_lower, alpha);
+                ba->ni = 2.0;
+                chi = temp;
+                ba->cur ^= 1; // discardTop: the trial state becomes the estimate
+            } else {
+                ba->lambda *= ba->ni;
+                ba->ni *= 2.0; // pop: estimate buffers untouched
+                if (!std::isfinite(ba->lambda)) { stop_inf = true; break; }
+            }
+            ++q;
+        } while (rho < 0 && q < o.lm_max_trials);
+        ba->stats.lm_iterations++;
+        ba->stats.lm_trials += (uint64_t)q;
+        ++done;
+        if (q == o.lm_max_trials || rho == 0 || stop_inf) break; // SolverResult::Terminate
+    }
+    if (performed) *performed = done;
+    return download_state(ba);
+}
+
+int add_proj(svi_ba* ba, int type, int64_t pose_id, int64_t lm_id, const double* z, const double* info, int robust)
+{
+    auto ip = ba->pose_ix.find(pose_id);
+    auto il = ba->lm_ix.find(lm_id);
+    if (ip == ba->pose_ix.end()) return fail(SVI_ERR_NOT_FOUND, "pose id %lld not in graph", (long long)pose_id);
+    if (il == ba->lm_ix.end()) return fail(SVI_ERR_NOT_FOUND, "landmark id %lld not in graph", (long long)lm_id);
+    HProj e{};
+    e.type = type; e.robust = robust ? 1 : 0; e.pose = ip->second; e.lm = il->second;
+    memcpy(e.z, z, 24); memcpy(e.info, info, 48);
+    ba->proj.push_back(e);
+    ba->initialized = false;
+    return SVI_OK;
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------
+// C ABI
+// ---------------------------------------------------------------------------------------------
+extern "C" {
+
+void svi_ba_options_default(svi_ba_options* o)
+{
+    if (!o) return;
+    memset(o, 0, sizeof(*o));
+    o->fx = o->fy = 1.0;
+    o->cauchy_delta = 1.0;
+    o->lm_tau = 1e-5; o->lm_good_step_lower = 1.0 / 3.0; o->lm_good_step_upper = 2.0 / 3.0; o->lm_max_trials = 10;
+    o->max_depth_xyz_l2 = 10.0; o->max_depth_uvdepth_l2 = 50.0; o->max_depth_uvdisp_l2 = 10000.0; o->sane_position_l2 = 1e12;
+    o->n_ranks = 1;
+    o->chol_tile = 96;
+}
+
+int svi_ba_create(const svi_ba_options* o, svi_ba** out)
+{
+    if (!o || !out) return fail(SVI_ERR_INVALID, "svi_ba_create: null argument");
+    *out = nullptr;
+    if (o->n_ranks < 1 || o->rank < 0 || o->rank >= o->n_ranks) return fail(SVI_ERR_INVALID, "bad rank %d / n_ranks %d", o->rank, o->n_ranks);
+    if (!(o->cauchy_delta > 0) || o->lm_max_trials < 1) return fail(SVI_ERR_INVALID, "bad LM / kernel options");
+    if (int rc = use_device(o->device)) return rc;
+    svi_ba* ba = new svi_ba();
+    ba->opt = *o;
+    if (ba->opt.chol_tile == 0) ba->opt.chol_tile = 96;
+    if (o->stream) ba->stream = static_cast<hipStream_t>(o->stream);
+    else {
+        hipError_t e = hipStreamCreateWithFlags(&ba->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete ba; return fail(SVI_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        ba->own_stream = true;
+    }
+    ba->timer.on = o->profile != 0;
+    *out = ba;
+    return SVI_OK;
+}
+
+int svi_ba_destroy(svi_ba* ba)
+{
+    if (!ba) return SVI_OK;
+    (void)hipSetDevice(ba->opt.device);
+    (void)hipStreamSynchronize(ba->stream);
+    free_device(ba);
+    ba->timer.release();
+    if (ba->own_stream) (void)hipStreamDestroy(ba->stream);
+    delete ba;
+    return SVI_OK;
+}
+
+int svi_ba_add_pose(svi_ba* ba, int64_t id, const double T[12], int fixed)
+{
+    if (!ba || !T) return fail(SVI_ERR_INVALID, "null argument");
+    if (ba->pose_ix.count(id) || ba->lm_ix.count(id)) return fail(SVI_ERR_INVALID, "vertex id %lld already in graph", (long long)id);
+    HPose p{};
+    p.id = id; memcpy(p.T, T, 96); p.fixed = fixed ? 1 : 0;
+    ba->pose_ix[id] = (int)ba->poses.size();
+    ba->poses.push_back(p);
+    ba->initialized = false;
+    return SVI_OK;
+}
+
+int svi_ba_add_landmark(svi_ba* ba, int64_t id, const double p[3], int fixed)
+{
+    if (!ba || !p) return fail(SVI_ERR_INVALID, "null argument");
+    if (ba->pose_ix.count(id) || ba->lm_ix.count(id)) return fail(SVI_ERR_INVALID, "vertex id %lld already in graph", (long long)id);
+    HLm l{};
+    l.id = id; memcpy(l.p, p, 24); l.fixed = fixed ? 1 : 0;
+    ba->lm_ix[id] = (int)ba->lms.size();
+    ba->lms.push_back(l);
+    ba->initialized = false;
+    return SVI_OK;
+}
+
+int svi_ba_add_edge_xyz(svi_ba* ba, int64_t pose_id, int64_t lm_id, const double z[3], const double info[6], int robust)
+{
+    if (!ba || !z || !info) return fail(SVI_ERR_INVALID, "null argument");
+    return add_proj(ba, kTypeXYZ, pose_id, lm_id, z, info, robust);
+}
+int svi_ba_add_edge_depth(svi_ba* ba, int64_t pose_id, int64_t lm_id, const double z[3], const double info[6], int robust)
+{
+    if (!ba || !z || !info) return fail(SVI_ERR_INVALID, "null argument");
+    return add_proj(ba, kTypeDepth, pose_id, lm_id, z, info, robust);
+}
+int svi_ba_add_edge_disparity(svi_ba* ba, int64_t pose_id, int64_t lm_id, const double z[3], const double info[6], int robust)
+{
+    if (!ba || !z || !info) return fail(SVI_ERR_INVALID, "null argument");
+    return add_proj(ba, kTypeDisparity, pose_id, lm_id, z, info, robust);
+}
+
+int svi_ba_add_edges_bulk(svi_ba* ba, int64_t n, const int32_t* type, const int64_t* pose_id, const int64_t* lm_id,
+                          const double* z, const double* info, const int32_t* robust)
+{
+    if (!ba || n < 0) return fail(SVI_ERR_INVALID, "bad argument");
+    if (n == 0) return SVI_OK;
+    if (!type || !pose_id || !lm_id || !z || !info) return fail(SVI_ERR_INVALID, "null argument");
+    const size_t before = ba->proj.size();
+    for (int64_t i = 0; i < n; ++i) {
+        if (type[i] < 0 || type[i] > 2) { ba->proj.resize(before); return fail(SVI_ERR_INVALID, "edge %lld: unknown type %d", (long long)i, type[i]); }
+        const int rc = add_proj(ba, type[i], pose_id[i], lm_id[i], z + 3 * i, info + 6 * i, robust ? robust[i] : 1);
+        if (rc != SVI_OK) { ba->proj.resize(before); return rc; }
+    }
+    return SVI_OK;
+}
+
+int svi_ba_add_edge_se3(svi_ba* ba, int64_t id_i, int64_t id_j, const double Z[12], const double info[21], int robust)
+{
+    if (!ba || !Z || !info) return fail(SVI_ERR_INVALID, "null argument");
+    auto i = ba->pose_ix.find(id_i), j = ba->pose_ix.find(id_j);
+    if (i == ba->pose_ix.end() || j == ba->pose_ix.end()) return fail(SVI_ERR_NOT_FOUND, "pose id not in graph");
+    if (i->second == j->second) return fail(SVI_ERR_INVALID, "EdgeSE3 between a pose and itself");
+    HSe3 e{};
+    e.i = i->second; e.j = j->second; e.robust = robust ? 1 : 0;
+    memcpy(e.Z, Z, 96); memcpy(e.info, info, 21 * 8);
+    ba->se3.push_back(e);
+    ba->initialized = false;
+    return SVI_OK;
+}
+
+int svi_ba_add_edge_accel(svi_ba* ba, int64_t pose_id, const double a[3], const double off[12], const double info[6])
+{
+    if (!ba || !a || !info) return fail(SVI_ERR_INVALID, "null argument");
+    auto i = ba->pose_ix.find(pose_id);
+    if (i == ba->pose_ix.end()) return fail(SVI_ERR_NOT_FOUND, "pose id %lld not in graph", (long long)pose_id);
+    HAcc e{};
+    e.pose = i->second;
+    memcpy(e.a, a, 24);
+    memcpy(e.off, off ? off : kIdentity12, 96);
+    memcpy(e.info, info, 48);
+    ba->acc.push_back(e);
+    ba->initialized = false;
+    return SVI_OK;
+}
+
+int svi_ba_add_edge_lm_lm(svi_ba* ba, int64_t id_i, int64_t id_j, const double z[3], const double info[6], int robust)
+{
+    if (!ba || !z || !info) return fail(SVI_ERR_INVALID, "null argument");
+    auto i = ba->lm_ix.find(id_i), j = ba->lm_ix.find(id_j);
+    if (i == ba->lm_ix.end() || j == ba->lm_ix.end()) return fail(SVI_ERR_NOT_FOUND, "landmark id not in graph");
+    if (i->second == j->second) return fail(SVI_ERR_INVALID, "EdgePointXYZ between a landmark and itself");
+    HLL e{};
+    e.i = i->second; e.j = j->second; e.robust = robust ? 1 : 0;
+    memcpy(e.z, z, 24); memcpy(e.info, info, 48);
+    ba->lmlm.push_back(e);
+    ba->initialized = false;
+    return SVI_OK;
+}
+
+// Cg2oOptimizer::_setAndgetPose (:1229-1290) + gravity edge (:480, :982-997)
+int svi_ba_add_keyframe(svi_ba* ba, int64_t id, int64_t from_id, const double T[12], const double shift[3], const double accel[3])
+{
+    if (!ba || !T) return fail(SVI_ERR_INVALID, "null argument");
+    auto f = ba->pose_ix.find(from_id);
+    if (f == ba->pose_ix.end()) return fail(SVI_ERR_NOT_FOUND, "previous keyframe id %lld not in graph", (long long)from_id);
+    double X[12];
+    memcpy(X, T, 96);
+    if (shift) { X[9] += shift[0]; X[10] += shift[1]; X[11] += shift[2]; } // :1233
+    SVI_TRY(svi_ba_add_pose(ba, id, X, 0));
+    const HPose& pf = ba->poses[f->second];
+    // measurement = Xfrom^-1 * Xcur (:1250)
+    double Z[12];
+    mat3T_mul(pf.T, X, Z);
+    const double d[3] = {X[9] - pf.T[9], X[10] - pf.T[10], X[11] - pf.T[11]};
+    for (int c = 0; c < 3; ++c) Z[9 + c] = pf.T[c] * d[0] + pf.T[3 + c] * d[1] + pf.T[6 + c] * d[2];
+    const double s = 1.0 / (1.0 + (Z[9] * Z[9] + Z[10] * Z[10] + Z[11] * Z[11])); // :1259
+    double info[21] = {0};
+    info[0] = info[6] = info[11] = 100000.0 * s; // m_matInformationPose (Cg2oOptimizer.cpp:72) scaled on the translation block (:1262-1263)
+    info[15] = info[18] = info[20] = 100000.0;
+    SVI_TRY(svi_ba_add_edge_se3(ba, from_id, id, Z, info, 0));
+    const double a0[3] = {0, 0, 0}, I3[6] = {1, 0, 0, 1, 0, 1};
+    return svi_ba_add_edge_accel(ba, id, accel ? accel : a0, nullptr, I3);
+}
+
+// Cg2oOptimizer::_setLandmarkMeasurementsWORLD (:1383-1466) with the factories (:999-1073)
+int svi_ba_add_measurements(svi_ba* ba, int64_t pose_id, int64_t n, const int64_t* lm_id, const float* uvL, const float* uvR,
+                            const double* xyz, int64_t stored[3])
+{
+    if (!ba || n < 0) return fail(SVI_ERR_INVALID, "bad argument");
+    if (stored) stored[0] = stored[1] = stored[2] = 0;
+    if (n == 0) return SVI_OK;
+    if (!lm_id || !uvL || !uvR || !xyz) return fail(SVI_ERR_INVALID, "null argument");
+    auto ip = ba->pose_ix.find(pose_id);
+    if (ip == ba->pose_ix.end()) return fail(SVI_ERR_NOT_FOUND, "pose id %lld not in graph", (long long)pose_id);
+    const svi_ba_options& o = ba->opt;
+    int64_t cnt[3] = {0, 0, 0};
+    for (int64_t m = 0; m < n; ++m) {
+        auto il = ba->lm_ix.find(lm_id[m]);
+        if (il == ba->lm_ix.end()) continue; // not in graph: silently skipped (:1393-1396)
+        const HPose& P = ba->poses[ip->second];
+        const HLm& L = ba->lms[il->second];
+        const double* pm = xyz + 3 * m;
+        double pe[3];
+        to_camera(P.T, P.T + 9, L.p, pe);
+        const double l2abs = pm[0] * pm[0] + pm[1] * pm[1] + pm[2] * pm[2];
+        const double l2rel = (pe[0] * pe[0] + pe[1] * pe[1] + pe[2] * pe[2]) / l2abs;
+        if (!(0.75 < l2rel && 1.25 > l2rel)) continue; // :1409
+        const double w = 1.0 / pm[2];                  // :1412
+        if (o.max_depth_xyz_l2 > l2abs) {              // :1415
+            const double info[6] = {w * 1000, 0, 0, w * 1000, 0, w * 1000};
+            SVI_TRY(add_proj(ba, kTypeXYZ, pose_id, lm_id[m], pm, info, 1));
+            cnt[0]++;
+        } else if (o.max_depth_uvdepth_l2 > l2abs) {   // :1426
+            const double z[3] = {(double)uvL[2 * m], (double)uvL[2 * m + 1], pm[2]};
+            const double info[6] = {w, 0, 0, w, 0, w * 100};
+            SVI_TRY(add_proj(ba, kTypeDepth, pose_id, lm_id[m], z, info, 1));
+            cnt[1]++;
+        } else if (o.max_depth_uvdisp_l2 > l2abs) {    // :1437
+            const double disp = (double)(uvL[2 * m] - uvR[2 * m]); // float difference, promoted (:1440)
+            if (1.0 < disp) {                          // :1443
+                const double z[3] = {(double)uvL[2 * m], (double)uvL[2 * m + 1], disp / (o.fx * o.baseline_m)}; // :1058
+                const double info[6] = {w, 0, 0, w, 0, w * 1000};
+                SVI_TRY(add_proj(ba, kTypeDisparity, pose_id, lm_id[m], z, info, 1));
+                cnt[2]++;
+            }
+        }
+    }
+    if (stored) { stored[0] = cnt[0]; stored[1] = cnt[1]; stored[2] = cnt[2]; }
+    return SVI_OK;
+}
+
+int svi_ba_initialize(svi_ba* ba)
+{
+    if (!ba) return fail(SVI_ERR_INVALID, "null handle");
+    if (int rc = use_device(ba->opt.device)) return rc;
+    free_device(ba);
+    ba->cur = 0;
+    ba->have_chi = false;
+    const int rc = build_structure(ba);
+    if (rc != SVI_OK) { free_device(ba); return rc; }
+    ba->initialized = true;
+    return SVI_OK;
+}
+
+int svi_ba_optimize(svi_ba* ba, int iterations, int* performed)
+{
+    if (!ba) return fail(SVI_ERR_INVALID, "null handle");
+    if (performed) *performed = 0;
+    if (iterations < 0) return fail(SVI_ERR_INVALID, "negative iteration count");
+    return optimize_block(ba, iterations, performed);
+}
+
+int svi_ba_optimize_until(svi_ba* ba, double ratio, int first, int block, uint64_t* nominal, uint64_t* executed)
+{
+    if (!ba) return fail(SVI_ERR_INVALID, "null handle");
+    if (first < 1 || block < 1) return fail(SVI_ERR_INVALID, "first and block must be >= 1");
+    uint64_t nom = 0, exe = 0;
+    int r = 0;
+    SVI_TRY(optimize_block(ba, first, &r)); // :960
+    nom += (uint64_t)first; exe += (uint64_t)r;
+    double prev = 1.1 * ba->last_plain;         // :966
+    while (ratio > ba->last_plain / prev) {     // :969
+        prev = ba->last_plain;                  // :972
+        SVI_TRY(optimize_block(ba, block, &r)); // :975
+        nom += (uint64_t)block; exe += (uint64_t)r;
+    }
+    if (nominal) *nominal = nom;
+    if (executed) *executed = exe;
+    return SVI_OK;
+}
+
+int svi_ba_chi2(svi_ba* ba, double* plain, double* robust)
+{
+    if (!ba) return fail(SVI_ERR_INVALID, "null handle");
+    if (!ba->initialized) return fail(SVI_ERR_STATE, "svi_ba_chi2 before svi_ba_initialize");
+    if (!ba->have_chi) { // nothing evaluated yet: evaluate the current estimate
+        SVI_HIP(hipSetDevice(ba->opt.device));
+        ba_chi2_only(ba->d, ba->cur, ba->stream);
+        ba_chi2_aux(ba->d, ba->cur, ba->opt.rank, ba->stream);
+        ba_reduce_trial_scalars(ba->d, ba->stream);
+        SVI_HIP(hipGetLastError());
+        SVI_TRY(allreduce(ba, ba->d.scal, 3));
+        SVI_TRY(read_scalars(ba, 8));
+        ba->last_robust = ba->h_scal[0]; ba->last_plain = ba->h_scal[1]; ba->have_chi = true;
+    }
+    if (plain) *plain = ba->last_plain;
+    if (robust) *robust = ba->last_robust;
+    return SVI_OK;
+}
+
+int svi_ba_lambda(svi_ba* ba, double* lambda)
+{
+    if (!ba || !lambda) return fail(SVI_ERR_INVALID, "null argument");
+    *lambda = ba->lambda;
+    return SVI_OK;
+}
+
+int svi_ba_get_pose(svi_ba* ba, int64_t id, double T[12])
+{
+    if (!ba || !T) return fail(SVI_ERR_INVALID, "null argument");
+    auto i = ba->pose_ix.find(id);
+    if (i == ba->pose_ix.end()) return fail(SVI_ERR_NOT_FOUND, "pose id %lld not in graph", (long long)id);
+    memcpy(T, ba->poses[i->second].T, 96);
+    return SVI_OK;
+}
+
+int svi_ba_get_landmark(svi_ba* ba, int64_t id, double p[3])
+{
+    if (!ba || !p) return fail(SVI_ERR_INVALID, "null argument");
+    auto i = ba->lm_ix.find(id);
+    if (i == ba->lm_ix.end()) return fail(SVI_ERR_NOT_FOUND, "landmark id %lld not in graph", (long long)id);
+    memcpy(p, ba->lms[i->second].p, 24);
+    return SVI_OK;
+}
+
+int svi_ba_num_poses(svi_ba* ba, int64_t* n) { if (!ba || !n) return fail(SVI_ERR_INVALID, "null argument"); *n = (int64_t)ba->poses.size(); return SVI_OK; }
+int svi_ba_num_landmarks(svi_ba* ba, int64_t* n) { if (!ba || !n) return fail(SVI_ERR_INVALID, "null argument"); *n = (int64_t)ba->lms.size(); return SVI_OK; }
+int svi_ba_num_edges(svi_ba* ba, int64_t* n)
+{
+    if (!ba || !n) return fail(SVI_ERR_INVALID, "null argument");
+    *n = (int64_t)(ba->proj.size() + ba->se3.size() + ba->acc.size() + ba->lmlm.size());
+    return SVI_OK;
+}
+
+int svi_ba_get_poses(svi_ba* ba, int64_t* ids, double* T)
+{
+    if (!ba || !T) return fail(SVI_ERR_INVALID, "null argument");
+    std::vector<int> ord(ba->poses.size());
+    std::iota(ord.begin(), ord.end(), 0);
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) { return ba->poses[a].id < ba->poses[b].id; });
+    for (size_t k = 0; k < ord.size(); ++k) { if (ids) ids[k] = ba->poses[ord[k]].id; memcpy(T + 12 * k, ba->poses[ord[k]].T, 96); }
+    return SVI_OK;
+}
+
+int svi_ba_get_landmarks(svi_ba* ba, int64_t* ids, double* p)
+{
+    if (!ba || !p) return fail(SVI_ERR_INVALID, "null argument");
+    std::vector<int> ord(ba->lms.size());
+    std::iota(ord.begin(), ord.end(), 0);
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) { return ba->lms[a].id < ba->lms[b].id; });
+    for (size_t k = 0; k < ord.size(); ++k) { if (ids) ids[k] = ba->lms[ord[k]].id; memcpy(p + 3 * k, ba->lms[ord[k]].p, 24); }
+    return SVI_OK;
+}
+
+// _applyOptimizationToLandmarks (:1486-1504): drop landmarks whose squared norm is not below 1e12
+int svi_ba_prune_diverged(svi_ba* ba, int64_t* removed)
+{
+    if (!ba) return fail(SVI_ERR_INVALID, "null handle");
+    const int nl = (int)ba->lms.size();
+    std::vector<int> remap(nl, -1);
+    int64_t gone = 0;
+    int k = 0;
+    for (int i = 0; i < nl; ++i) {
+        const double* p = ba->lms[i].p;
+        if (ba->opt.sane_position_l2 > p[0] * p[0] + p[1] * p[1] + p[2] * p[2]) remap[i] = k++;
+        else ++gone;
+    }
+    if (gone) {
+        std::vector<HLm> keep;
+        keep.reserve(k);
+        ba->lm_ix.clear();
+        for (int i = 0; i < nl; ++i) if (remap[i] >= 0) { ba->lm_ix[ba->lms[i].id] = (int)keep.size(); keep.push_back(ba->lms[i]); }
+        ba->lms.swap(keep);
+        std::vector<HProj> pe;
+        pe.reserve(ba->proj.size());
+        for (HProj e : ba->proj) if (remap[e.lm] >= 0) { e.lm = remap[e.lm]; pe.push_back(e); }
+        ba->proj.swap(pe);
+        std::vector<HLL> le;
+        for (HLL e : ba->lmlm) if (remap[e.i] >= 0 && remap[e.j] >= 0) { e.i = remap[e.i]; e.j = remap[e.j]; le.push_back(e); }
+        ba->lmlm.swap(le);
+        ba->initialized = false;
+    }
+    if (removed) *removed = gone;
+    return SVI_OK;
+}
+
+int svi_ba_set_allreduce(svi_ba* ba, svi_allreduce_fn fn, void* user)
+{
+    if (!ba) return fail(SVI_ERR_INVALID, "null handle");
+    ba->ar = fn; ba->ar_user = user;
+    return SVI_OK;
+}
+
+int svi_ba_get_phase_times(svi_ba* ba, double ms[SVI_PH_COUNT], int64_t calls[SVI_PH_COUNT])
+{
+    if (!ba) return fail(SVI_ERR_INVALID, "null handle");
+    for (int i = 0; i < SVI_PH_COUNT; ++i) { if (ms) ms[i] = ba->timer.ms[i]; if (calls) calls[i] = ba->timer.calls[i]; }
+    return SVI_OK;
+}
+
+int svi_ba_reset_phase_times(svi_ba* ba)
+{
+    if (!ba) return fail(SVI_ERR_INVALID, "null handle");
+    for (int i = 0; i < SVI_PH_COUNT; ++i) { ba->timer.ms[i] = 0.0; ba->timer.calls[i] = 0; }
+    return SVI_OK;
+}
+
+int svi_ba_get_stats(svi_ba* ba, svi_ba_stats* s)
+{
+    if (!ba || !s) return fail(SVI_ERR_INVALID, "null argument");
+    *s = ba->stats;
+    s->n_poses = (int64_t)ba->poses.size();
+    s->n_landmarks = (int64_t)ba->lms.size();
+    s->n_edges_proj = (int64_t)ba->proj.size();
+    s->n_edges_se3 = (int64_t)ba->se3.size(); s->n_edges_accel = (int64_t)ba->acc.size(); s->n_edges_lmlm = (int64_t)ba->lmlm.size();
+    return SVI_OK;
+}
+
+int svi_ba_debug_edge_jacobians(svi_ba* ba, double* err, double* J_pose, double* J_lm)
+{
+    if (!ba || !err || !J_pose || !J_lm) return fail(SVI_ERR_INVALID, "null argument");
+    if (!ba->initialized) return fail(SVI_ERR_STATE, "debug tap before svi_ba_initialize");
+    SVI_HIP(hipSetDevice(ba->opt.device));
+    const size_t E = ba->proj.size();
+    double *de = nullptr, *dp = nullptr, *dl = nullptr;
+    SVI_HIP(hipMalloc(reinterpret_cast<void**>(&de), sizeof(double) * 30 * std::max<size_t>(E, 1)));
+    dp = de + 3 * E; dl = dp + 18 * E;
+    hipError_t e1 = hipMemsetAsync(de, 0, sizeof(double) * 30 * std::max<size_t>(E, 1), ba->stream);
+    ba_debug_jacobians(ba->d, ba->cur, ba->e_orig, de, dp, dl, ba->stream);
+    hipError_t e2 = hipMemcpyAsync(err, de, sizeof(double) * 3 * E, hipMemcpyDeviceToHost, ba->stream);
+    hipError_t e3 = hipMemcpyAsync(J_pose, dp, sizeof(double) * 18 * E, hipMemcpyDeviceToHost, ba->stream);
+    hipError_t e4 = hipMemcpyAsync(J_lm, dl, sizeof(double) * 9 * E, hipMemcpyDeviceToHost, ba->stream);
+    hipError_t e5 = hipStreamSynchronize(ba->stream);
+    (void)hipFree(de);
+    if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess)
+        return fail(SVI_ERR_HIP, "debug_edge_jacobians: HIP failure");
+    return SVI_OK;
+}
+
+// linearise at the current estimate, reduce with damping lambda, return dense S (with lambda on its
+// diagonal) and g
+int svi_ba_debug_reduced_system(svi_ba* ba, double lambda, double* S, double* g, int64_t cap, int64_t* n_out)
+{
+    if (!ba || !S || !g || !n_out) return fail(SVI_ERR_INVALID, "null argument");
+    if (!ba->initialized) return fail(SVI_ERR_STATE, "debug tap before svi_ba_initialize");
+    SVI_HIP(hipSetDevice(ba->opt.device));
+    BaDev& d = ba->d;
+    const int64_t n = 6 * (int64_t)d.Pf;
+    *n_out = n;
+    if (cap < n) return fail(SVI_ERR_INVALID, "capacity %lld < n %lld", (long long)cap, (long long)n);
+    SVI_TRY(linearize(ba));
+    SVI_HIP(hipMemsetAsync(d.chol_status, 0, sizeof(int), ba->stream));
+    ba_invert_landmarks(d, lambda, ba->stream);
+    ba_schur(d, ba->stream);
+    ba_assemble(d, ba->stream);
+    SVI_HIP(hipGetLastError());
+    SVI_TRY(allreduce(ba, d.S, (size_t)d.red_count));
+    const int TS = d.TS, NT = d.NT;
+    std::vector<double> tiles((size_t)d.n_tiles * TS * TS), gv((size_t)NT * TS);
+    std::vector<int> tmap((size_t)NT * NT);
+    if (d.n_tiles) SVI_HIP(hipMemcpyAsync(tiles.data(), d.S, sizeof(double) * tiles.size(), hipMemcpyDeviceToHost, ba->stream));
+    if (NT) SVI_HIP(hipMemcpyAsync(gv.data(), d.g, sizeof(double) * gv.size(), hipMemcpyDeviceToHost, ba->stream));
+    if (NT) SVI_HIP(hipMemcpyAsync(tmap.data(), d.tile_map, sizeof(int) * tmap.size(), hipMemcpyDeviceToHost, ba->stream));
+    SVI_HIP(hipStreamSynchronize(ba->stream));
+    for (int64_t i = 0; i < n * n; ++i) S[i] = 0.0;
+    for (int ti = 0; ti < NT; ++ti)
+        for (int tj = 0; tj <= ti; ++tj) {
+            const int t = tmap[(size_t)ti * NT + tj];
+            if (t < 0) continue;
+            for (int r = 0; r < TS; ++r)
+                for (int c = 0; c < TS; ++c) {
+                    const int64_t R = (int64_t)ti * TS + r, Cc = (int64_t)tj * TS + c;
+                    if (R >= n || Cc >= n || Cc > R) continue;
+                    const double v = tiles[(size_t)t * TS * TS + (size_t)r * TS + c];
+                    S[R * n + Cc] = v; S[Cc * n + R] = v;
+                }
+        }
+    for (int64_t i = 0; i < n; ++i) { S[i * n + i] += lambda; g[i] = gv[i]; }
+    return SVI_OK;
+}
+
+} // extern "C"

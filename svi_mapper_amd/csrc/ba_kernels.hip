@@ -1,0 +1,814 @@
+// ba_kernels.hip — bundle-adjustment sweeps for gfx950 (MI355X): linearisation, Schur reduction,
+// back-substitution, update and chi2.  Replaces what g2o does inside
+//   SparseOptimizer::computeActiveErrors / BlockSolver::buildSystem / SparseOptimizer::update
+// when driven by Cg2oOptimizer::_optimizeUnLimited (src/optimization/Cg2oOptimizer.cpp:954-980)
+// with the solver stack configured at Cg2oOptimizer.cpp:83-89.  Edge semantics follow the
+// reference's factories (Cg2oOptimizer.cpp:982-1073) and the g2o slam3d types as restated in
+// SURVEY.md Appendix B.
+//
+// All of these kernels are HBM-streaming FP64 code: SoA edge arrays read with one coalesced 8 B
+// load per lane and plane, outputs written as planes, vertex data (poses: 96 B, landmarks: 24 B)
+// served from L1/L2.  Reductions are two-stage and fixed-order (per-workgroup partials, then one
+// workgroup), so results do not depend on scheduling; the only atomics are LDS adds inside the
+// Schur workgroups.
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "ba_device.h"
+#include "ba_math.h"
+
+namespace svi {
+namespace {
+
+constexpr int kBlock = 256;
+
+// ---------------------------------------------------------------------------------------------
+// block-wide sum of NV doubles held by every thread; result valid in thread 0. Fixed order.
+template <int NV>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* s_red /* [NV][4] */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+        double x = v[k];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+        if (lane == 0) s_red[k * 4 + wave] = x;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int k = 0; k < NV; ++k) v[k] = (s_red[k * 4] + s_red[k * 4 + 1]) + (s_red[k * 4 + 2] + s_red[k * 4 + 3]);
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ double block_max(double x, double* s_red /* [4] */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) x = fmax(x, __shfl_down(x, off, 64));
+    if (lane == 0) s_red[wave] = x;
+    __syncthreads();
+    const double r = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+    __syncthreads();
+    return r;
+}
+
+struct EdgeIn {
+    double z[3];
+    double info[6]; // upper triangle 00 01 02 11 12 22
+    int    type;
+    bool   robust;
+};
+
+__device__ __forceinline__ void load_edge(const double* __restrict__ zp, const double* __restrict__ ip, int planes,
+                                          const uint8_t* __restrict__ flags, int E, int e, EdgeIn& in)
+{
+    in.z[0] = zp[e]; in.z[1] = zp[E + e]; in.z[2] = zp[2 * E + e];
+    if (planes == 3) {
+        in.info[0] = ip[e]; in.info[3] = ip[E + e]; in.info[5] = ip[2 * E + e];
+        in.info[1] = in.info[2] = in.info[4] = 0.0;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) in.info[k] = ip[k * E + e];
+    }
+    const unsigned f = flags[e];
+    in.type = f & kFlagTypeMask;
+    in.robust = (f & kFlagRobust) != 0;
+}
+
+// chi2 = e' Omega e ; weight rho1 and rho0 of g2o's RobustKernelCauchy
+__device__ __forceinline__ double edge_chi2(const EdgeIn& in, const double* e)
+{
+    return e[0] * (in.info[0] * e[0] + 2.0 * (in.info[1] * e[1] + in.info[2] * e[2])) +
+           e[1] * (in.info[3] * e[1] + 2.0 * in.info[4] * e[2]) + e[2] * in.info[5] * e[2];
+}
+
+// ---------------------------------------------------------------------------------------------
+// K2: landmark-major Jacobian sweep.  One lane per edge, one workgroup per run of whole landmarks.
+// Writes H_pl (18 planes), H_ll (6 planes), b_l (3 planes); per-workgroup partial chi2 / max diag.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_linearize_lm(BaDev d, int cur)
+{
+    __shared__ double s_acc[9][kLmBlockEdges];
+    __shared__ double s_red[3 * 4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int l0 = d.lb_lm[b], l1 = d.lb_lm[b + 1];
+    const int e0 = d.lm_ptr[l0], e1 = d.lm_ptr[l1];
+    const double* __restrict__ pose = d.pose[cur];
+    const double* __restrict__ lm = d.lm[cur];
+    const int E = d.E;
+
+    double part[3] = {0.0, 0.0, 0.0}; // robust chi2, plain chi2
+    const int e = e0 + tid;
+    if (e < e1) {
+        EdgeIn in;
+        load_edge(d.e_z, d.e_info, d.info_planes, d.e_flags, E, e, in);
+        const int s = d.e_pose[e], l = d.e_lm[e];
+        double R[9], t[3], p[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = pose[12 * s + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { t[k] = pose[12 * s + 9 + k]; p[k] = lm[3 * l + k]; }
+        double err[3], J[27];
+        proj_eval(in.type, R, t, p, in.z, d.fx, d.fy, d.cx, d.cy, err, J);
+        const double c2 = edge_chi2(in, err);
+        double w = 1.0, r0 = c2;
+        if (in.robust) cauchy(d.cauchy_delta, c2, r0, w);
+        part[0] = r0; part[1] = c2;
+        const bool lfix = d.lm_fixed[l] != 0;
+        // OJ = (w Omega) J   (3 x 9)
+        double O[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) O[k] = w * in.info[k];
+        double OJ[27];
+#pragma unroll
+        for (int c = 0; c < 9; ++c) {
+            OJ[c]      = O[0] * J[c] + O[1] * J[9 + c] + O[2] * J[18 + c];
+            OJ[9 + c]  = O[1] * J[c] + O[3] * J[9 + c] + O[4] * J[18 + c];
+            OJ[18 + c] = O[2] * J[c] + O[4] * J[9 + c] + O[5] * J[18 + c];
+        }
+        const double Oe[3] = {O[0] * err[0] + O[1] * err[1] + O[2] * err[2], O[1] * err[0] + O[3] * err[1] + O[4] * err[2],
+                              O[2] * err[0] + O[4] * err[1] + O[5] * err[2]};
+        // H_pl = J_p' OJ_l  (6 x 3)
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                const double v = J[a] * OJ[6 + c] + J[9 + a] * OJ[15 + c] + J[18 + a] * OJ[24 + c];
+                d.W[(size_t)(3 * a + c) * E + e] = lfix ? 0.0 : v;
+            }
+        // H_ll contribution (upper 00 01 02 11 12 22) and b_l = -J_l' Oe
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int c = a; c < 3; ++c, ++k)
+                s_acc[k][tid] = J[6 + a] * OJ[6 + c] + J[15 + a] * OJ[15 + c] + J[24 + a] * OJ[24 + c];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) s_acc[6 + c][tid] = -(J[6 + c] * Oe[0] + J[15 + c] * Oe[1] + J[24 + c] * Oe[2]);
+    }
+    __syncthreads();
+    double mx = 0.0;
+    const int l = l0 + tid;
+    if (l < l1) {
+        double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        const int a0 = d.lm_ptr[l] - e0, a1 = d.lm_ptr[l + 1] - e0;
+        for (int a = a0; a < a1; ++a) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[k] += s_acc[k][a];
+        }
+        // landmark-closure priors (EdgePointXYZ with a fixed partner, Cg2oOptimizer.cpp:448-458)
+        for (int q = d.lm_ll_ptr[l]; q < d.lm_ll_ptr[l + 1]; ++q) {
+            double ee[3], O[6];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ee[k] = lm[3 * l + k] - d.ll_ref[3 * q + k] - d.ll_z[3 * q + k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) O[k] = d.ll_info[6 * q + k];
+            const double c2 = ee[0] * (O[0] * ee[0] + 2.0 * (O[1] * ee[1] + O[2] * ee[2])) +
+                              ee[1] * (O[3] * ee[1] + 2.0 * O[4] * ee[2]) + ee[2] * O[5] * ee[2];
+            double w = 1.0, r0 = c2;
+            if (d.ll_robust[q]) cauchy(d.cauchy_delta, c2, r0, w);
+            part[0] += r0; part[1] += c2;
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[k] += w * O[k];
+            acc[6] -= w * (O[0] * ee[0] + O[1] * ee[1] + O[2] * ee[2]);
+            acc[7] -= w * (O[1] * ee[0] + O[3] * ee[1] + O[4] * ee[2]);
+            acc[8] -= w * (O[2] * ee[0] + O[4] * ee[1] + O[5] * ee[2]);
+        }
+        if (d.lm_fixed[l]) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) acc[k] = 0.0;
+        }
+        const int Ll = d.Ll;
+#pragma unroll
+        for (int k = 0; k < 6; ++k) d.Hll[(size_t)k * Ll + l] = acc[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d.bl[(size_t)k * Ll + l] = acc[6 + k];
+        mx = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
+    }
+    part[2] = 0.0;
+    block_sum<3>(part, s_red);
+    const double bm = block_max(mx, s_red);
+    if (tid == 0) {
+        d.block_part[4 * b + 0] = part[0];
+        d.block_part[4 * b + 1] = part[1];
+        d.block_part[4 * b + 2] = bm;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K3: pose-major Jacobian sweep: one workgroup per chunk of <= kPoseChunk edges of ONE pose.
+// Sums J_p' (rho1 Omega) J_p (21) and -J_p' rho1 Omega e (6) in a fixed order.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_linearize_pose(BaDev d, int cur)
+{
+    __shared__ double s_part[27][kBlock + 1];
+    __shared__ double s_q[27][4];
+    const int c = blockIdx.x, tid = threadIdx.x;
+    const int s = d.chunk_pose[c];
+    const int e0 = d.chunk_begin[c], e1 = d.chunk_begin[c + 1];
+    const double* __restrict__ pose = d.pose[cur];
+    const double* __restrict__ lm = d.lm[cur];
+    const int E = d.E;
+    double R[9], t[3];
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = pose[12 * s + k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) t[k] = pose[12 * s + 9 + k];
+
+    double acc[27];
+#pragma unroll
+    for (int k = 0; k < 27; ++k) acc[k] = 0.0;
+    for (int e = e0 + tid; e < e1; e += kBlock) {
+        EdgeIn in;
+        load_edge(d.pm_z, d.pm_info, d.info_planes, d.pm_flags, E, e, in);
+        const int l = d.pm_lm[e];
+        const double p[3] = {lm[3 * l], lm[3 * l + 1], lm[3 * l + 2]};
+        double err[3], J[27];
+        proj_eval(in.type, R, t, p, in.z, d.fx, d.fy, d.cx, d.cy, err, J);
+        double w = 1.0, r0;
+        if (in.robust) cauchy(d.cauchy_delta, edge_chi2(in, err), r0, w);
+        double O[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) O[k] = w * in.info[k];
+        double OJ[18]; // (w Omega) J_p : 3 x 6
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            OJ[a]      = O[0] * J[a] + O[1] * J[9 + a] + O[2] * J[18 + a];
+            OJ[6 + a]  = O[1] * J[a] + O[3] * J[9 + a] + O[4] * J[18 + a];
+            OJ[12 + a] = O[2] * J[a] + O[4] * J[9 + a] + O[5] * J[18 + a];
+        }
+        int k = 0;
+#pragma unroll
+        for (int a = 0; a < 6; ++a)
+#pragma unroll
+            for (int b = a; b < 6; ++b, ++k) acc[k] += J[a] * OJ[b] + J[9 + a] * OJ[6 + b] + J[18 + a] * OJ[12 + b];
+#pragma unroll
+        for (int a = 0; a < 6; ++a) acc[21 + a] -= OJ[a] * err[0] + OJ[6 + a] * err[1] + OJ[12 + a] * err[2];
+    }
+#pragma unroll
+    for (int k = 0; k < 27; ++k) s_part[k][tid] = acc[k];
+    __syncthreads();
+    if (tid < 27 * 4) {
+        const int k = tid >> 2, q = tid & 3;
+        double sum = 0.0;
+        for (int i = 0; i < 64; ++i) sum += s_part[k][q * 64 + i];
+        s_q[k][q] = sum;
+    }
+    __syncthreads();
+    if (tid < 27) d.chunk_out[(size_t)27 * c + tid] = (s_q[tid][0] + s_q[tid][1]) + (s_q[tid][2] + s_q[tid][3]);
+}
+
+// ---------------------------------------------------------------------------------------------
+// pose-only edges (odometry EdgeSE3, gravity EdgeSE3LinearAcceleration): a single workgroup,
+// LINEARIZE: also the quadratic forms.  Writes aux chi2 (robust, plain) to d.scal[6], d.scal[7].
+// ---------------------------------------------------------------------------------------------
+template <bool LINEARIZE>
+__global__ __launch_bounds__(kBlock) void k_aux_edges(BaDev d, int which)
+{
+    __shared__ double s_red[2 * 4];
+    const double* __restrict__ pose = d.pose[which];
+    double part[2] = {0.0, 0.0};
+    for (int k = threadIdx.x; k < d.n_se3; k += kBlock) {
+        const int si = d.se3_i[k], sj = d.se3_j[k];
+        double e[6], Ji[36], Jj[36], O[36];
+        se3_edge_eval(pose + 12 * si, pose + 12 * sj, d.se3_Z + 12 * k, e, LINEARIZE ? Ji : nullptr, Jj);
+        int q = 0;
+        for (int r = 0; r < 6; ++r)
+            for (int c = r; c < 6; ++c, ++q) O[6 * r + c] = O[6 * c + r] = d.se3_info[21 * k + q];
+        double c2 = 0.0;
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) c2 += e[r] * O[6 * r + c] * e[c];
+        double w = 1.0, r0 = c2;
+        if (d.se3_robust[k]) cauchy(d.cauchy_delta, c2, r0, w);
+        part[0] += r0; part[1] += c2;
+        if (LINEARIZE) {
+            double* out = d.se3_out + (size_t)120 * k;
+            double Oe[6], OJi[36], OJj[36];
+            for (int r = 0; r < 6; ++r) {
+                double sacc = 0.0;
+                for (int c = 0; c < 6; ++c) sacc += w * O[6 * r + c] * e[c];
+                Oe[r] = sacc;
+                for (int c = 0; c < 6; ++c) {
+                    double a = 0.0, b = 0.0;
+                    for (int m = 0; m < 6; ++m) { a += w * O[6 * r + m] * Ji[6 * m + c]; b += w * O[6 * r + m] * Jj[6 * m + c]; }
+                    OJi[6 * r + c] = a; OJj[6 * r + c] = b;
+                }
+            }
+            for (int r = 0; r < 6; ++r)
+                for (int c = 0; c < 6; ++c) {
+                    double hii = 0.0, hjj = 0.0, hij = 0.0;
+                    for (int m = 0; m < 6; ++m) {
+                        hii += Ji[6 * m + r] * OJi[6 * m + c];
+                        hjj += Jj[6 * m + r] * OJj[6 * m + c];
+                        hij += Ji[6 * m + r] * OJj[6 * m + c];
+                    }
+                    out[6 * r + c] = hii; out[36 + 6 * r + c] = hjj; out[72 + 6 * r + c] = hij;
+                }
+            for (int r = 0; r < 6; ++r) {
+                double bi = 0.0, bj = 0.0;
+                for (int m = 0; m < 6; ++m) { bi += Ji[6 * m + r] * Oe[m]; bj += Jj[6 * m + r] * Oe[m]; }
+                out[108 + r] = -bi; out[114 + r] = -bj;
+            }
+        }
+    }
+    for (int k = threadIdx.x; k < d.n_accel; k += kBlock) {
+        const int s = d.acc_pose[k];
+        const double* R = pose + 12 * s;
+        const double v[3] = {d.acc_a[3 * k], d.acc_a[3 * k + 1], d.acc_a[3 * k + 2]};
+        // e = R v - (0,0,-1)   (edge_se3_linear_acceleration.cpp:106-116)
+        const double e[3] = {R[0] * v[0] + R[1] * v[1] + R[2] * v[2], R[3] * v[0] + R[4] * v[1] + R[5] * v[2],
+                             R[6] * v[0] + R[7] * v[1] + R[8] * v[2] + 1.0};
+        double O[6];
+        for (int q = 0; q < 6; ++q) O[q] = d.acc_info[6 * k + q];
+        const double c2 = e[0] * (O[0] * e[0] + 2.0 * (O[1] * e[1] + O[2] * e[2])) + e[1] * (O[3] * e[1] + 2.0 * O[4] * e[2]) +
+                          e[2] * O[5] * e[2];
+        part[0] += c2; part[1] += c2;
+        if (LINEARIZE) {
+            // d e / d dq = -2 R [v]x ; d e / d dt = 0
+            const double S[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+            double J[18];
+            for (int r = 0; r < 3; ++r) {
+                J[6 * r] = J[6 * r + 1] = J[6 * r + 2] = 0.0;
+                for (int c = 0; c < 3; ++c) J[6 * r + 3 + c] = -2.0 * (R[3 * r] * S[c] + R[3 * r + 1] * S[3 + c] + R[3 * r + 2] * S[6 + c]);
+            }
+            const double Of[9] = {O[0], O[1], O[2], O[1], O[3], O[4], O[2], O[4], O[5]};
+            double* out = d.acc_out + (size_t)42 * k;
+            for (int r = 0; r < 6; ++r) {
+                for (int c = 0; c < 6; ++c) {
+                    double h = 0.0;
+                    for (int m = 0; m < 3; ++m)
+                        for (int n = 0; n < 3; ++n) h += J[6 * m + r] * Of[3 * m + n] * J[6 * n + c];
+                    out[6 * r + c] = h;
+                }
+                double bb = 0.0;
+                for (int m = 0; m < 3; ++m)
+                    for (int n = 0; n < 3; ++n) bb += J[6 * m + r] * Of[3 * m + n] * e[n];
+                out[36 + r] = -bb;
+            }
+        }
+    }
+    block_sum<2>(part, s_red);
+    if (threadIdx.x == 0) { d.scal[6] = part[0]; d.scal[7] = part[1]; }
+}
+
+// H_pp / b_p of every free pose = sum of its chunk partials (fixed order) + its pose-only edges.
+__global__ __launch_bounds__(kBlock) void k_pose_finalize(BaDev d, const int* __restrict__ red_slot)
+{
+    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    if (idx >= d.Pf * 27) return;
+    const int r = idx / 27, v = idx % 27;
+    const int s = red_slot[r];
+    double sum = 0.0;
+    for (int c = d.pose_chunk_ptr[s]; c < d.pose_chunk_ptr[s + 1]; ++c) sum += d.chunk_out[(size_t)27 * c + v];
+    // position of upper-triangle entry v in a full 6x6
+    int rr = 0, cc = 0;
+    if (v < 21) {
+        int k = v;
+        rr = 0;
+        while (k >= 6 - rr) { k -= 6 - rr; ++rr; }
+        cc = rr + k;
+    }
+    for (int q = d.pose_aux_ptr[s]; q < d.pose_aux_ptr[s + 1]; ++q) {
+        const int ref = d.pose_aux_ref[q], k = ref >> 2, role = ref & 3;
+        if (role == 2) sum += (v < 21) ? d.acc_out[(size_t)42 * k + 6 * rr + cc] : d.acc_out[(size_t)42 * k + 36 + (v - 21)];
+        else {
+            const double* o = d.se3_out + (size_t)120 * k;
+            sum += (v < 21) ? o[36 * role + 6 * rr + cc] : o[108 + 6 * role + (v - 21)];
+        }
+    }
+    if (v < 21) d.Hpp[(size_t)21 * r + v] = sum;
+    else d.bp[(size_t)6 * r + (v - 21)] = sum;
+}
+
+// chi2 (robust, plain) of the linearisation point and this rank's max |diag H_ll|.
+__global__ __launch_bounds__(kBlock) void k_reduce_lin_scalars(BaDev d, int rank, int n_ranks)
+{
+    __shared__ double s_red[2 * 4];
+    double part[2] = {0.0, 0.0};
+    double mx = 0.0;
+    for (int b = threadIdx.x; b < d.n_lm_blocks; b += kBlock) {
+        part[0] += d.block_part[4 * b];
+        part[1] += d.block_part[4 * b + 1];
+        mx = fmax(mx, d.block_part[4 * b + 2]);
+    }
+    block_sum<2>(part, s_red);
+    mx = block_max(mx, s_red);
+    if (threadIdx.x == 0) {
+        d.lin_scal[0] = part[0] + d.scal[6];
+        d.lin_scal[1] = part[1] + d.scal[7];
+        for (int k = 0; k < n_ranks; ++k) d.lin_scal[2 + k] = (k == rank) ? mx : 0.0;
+    }
+}
+
+// max |H_jj| over all free vertices (g2o computeLambdaInit) -> scal[5]; also copies chi2 to scal[0..1]
+__global__ __launch_bounds__(kBlock) void k_lin_post(BaDev d, int n_ranks)
+{
+    __shared__ double s_red[4];
+    double mx = 0.0;
+    for (int i = threadIdx.x; i < d.Pf * 6; i += kBlock) {
+        const int r = i / 6, a = i % 6;
+        // diagonal entry a of the upper-triangle packing: index = a*6 - a(a-1)/2
+        mx = fmax(mx, fabs(d.Hpp[(size_t)21 * r + (a * 6 - a * (a - 1) / 2)]));
+    }
+    for (int k = threadIdx.x; k < n_ranks; k += kBlock) mx = fmax(mx, d.lin_scal[2 + k]);
+    mx = block_max(mx, s_red);
+    if (threadIdx.x == 0) { d.scal[5] = mx; d.scal[0] = d.lin_scal[0]; d.scal[1] = d.lin_scal[1]; }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4a: (H_ll + lambda I)^-1 per landmark (upper triangle). A non positive definite block marks the
+// trial as failed, like the factorisation of the full system would.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_invert_landmarks(BaDev d, double lambda)
+{
+    const int l = blockIdx.x * kBlock + threadIdx.x;
+    if (l >= d.Ll) return;
+    const size_t Ll = d.Ll;
+    double inv[6] = {0, 0, 0, 0, 0, 0};
+    if (!d.lm_fixed[l]) {
+        const double a = d.Hll[l] + lambda, b = d.Hll[Ll + l], c = d.Hll[2 * Ll + l];
+        const double e = d.Hll[3 * Ll + l] + lambda, f = d.Hll[4 * Ll + l], i = d.Hll[5 * Ll + l] + lambda;
+        const double c00 = e * i - f * f, c01 = c * f - b * i, c02 = b * f - c * e;
+        const double det = a * c00 + b * c01 + c * c02;
+        const double m1 = a * e - b * b;
+        if (!(a > 0.0) || !(m1 > 0.0) || !(det > 0.0)) { *d.chol_status = -1; }
+        else {
+            const double id = 1.0 / det;
+            inv[0] = c00 * id; inv[1] = c01 * id; inv[2] = c02 * id;
+            inv[3] = (a * i - c * c) * id; inv[4] = (b * c - a * f) * id; inv[5] = m1 * id;
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 6; ++k) d.Hinv[(size_t)k * Ll + l] = inv[k];
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4: Schur reduction, S-tile major.  One workgroup per job = a batch of (landmark, row segment,
+// column segment) items that all fall into one TS x TS tile of S.  Each lane takes one pose pair
+// (a,b) of one landmark:  block = (W_a Hinv_l) W_b'  (6x6), accumulated in an LDS image of the tile
+// with ds_add_f64, then the tile image is stored to this job's slab.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
+{
+    extern __shared__ __align__(16) double s_tile[]; // [TS*TS] + [TS]
+    const int TS = d.TS, PB = TS / 6;
+    double* s_g = s_tile + TS * TS;
+    const int job = blockIdx.x, tid = threadIdx.x;
+    for (int i = tid; i < TS * TS + TS; i += kBlock) s_tile[i] = 0.0;
+    __syncthreads();
+
+    const int it0 = d.job_item0[job], it1 = d.job_item0[job + 1];
+    const int p0 = d.job_pair0[it0], p1 = d.job_pair0[it1];
+    const bool diag = d.job_ti[job] == d.job_tj[job];
+    const size_t E = d.E, Ll = d.Ll;
+    for (int p = p0 + tid; p < p1; p += kBlock) {
+        // item containing pair p
+        int lo = it0, hi = it1 - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (d.job_pair0[mid] <= p) lo = mid; else hi = mid - 1;
+        }
+        const int it = lo, q = p - d.job_pair0[it];
+        int al, bl_;
+        if (diag) { // lower triangle incl. diagonal: q = al(al+1)/2 + bl
+            al = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
+            while ((al + 1) * (al + 2) / 2 <= q) ++al;
+            while (al * (al + 1) / 2 > q) --al;
+            bl_ = q - al * (al + 1) / 2;
+        } else {
+            const int nb = d.it_nb[it];
+            al = q / nb; bl_ = q - al * nb;
+        }
+        const int ea = d.it_a0[it] + al, eb = d.it_b0[it] + bl_;
+        const int l = d.it_lm[it];
+        const int ra = d.pose_red[d.e_pose[ea]], rb = d.pose_red[d.e_pose[eb]];
+        const int li = (ra % PB) * 6, lj = (rb % PB) * 6;
+        double Hi[6];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) Hi[k] = d.Hinv[(size_t)k * Ll + l];
+        double T[18]; // W_a Hinv
+#pragma unroll
+        for (int i = 0; i < 6; ++i) {
+            const double w0 = d.W[(size_t)(3 * i) * E + ea], w1 = d.W[(size_t)(3 * i + 1) * E + ea], w2 = d.W[(size_t)(3 * i + 2) * E + ea];
+            T[3 * i]     = w0 * Hi[0] + w1 * Hi[1] + w2 * Hi[2];
+            T[3 * i + 1] = w0 * Hi[1] + w1 * Hi[3] + w2 * Hi[4];
+            T[3 * i + 2] = w0 * Hi[2] + w1 * Hi[4] + w2 * Hi[5];
+        }
+#pragma unroll
+        for (int j = 0; j < 6; ++j) {
+            const double w0 = d.W[(size_t)(3 * j) * E + eb], w1 = d.W[(size_t)(3 * j + 1) * E + eb], w2 = d.W[(size_t)(3 * j + 2) * E + eb];
+#pragma unroll
+            for (int i = 0; i < 6; ++i)
+                atomicAdd(&s_tile[(li + i) * TS + lj + j], T[3 * i] * w0 + T[3 * i + 1] * w1 + T[3 * i + 2] * w2);
+        }
+        if (diag && al == bl_) {
+            const double b0 = d.bl[l], b1 = d.bl[Ll + l], b2 = d.bl[2 * Ll + l];
+#pragma unroll
+            for (int i = 0; i < 6; ++i) atomicAdd(&s_g[li + i], T[3 * i] * b0 + T[3 * i + 1] * b1 + T[3 * i + 2] * b2);
+        }
+    }
+    __syncthreads();
+    double* out = d.slab + (size_t)job * TS * TS;
+    for (int i = tid; i < TS * TS; i += kBlock) out[i] = s_tile[i];
+    if (diag) for (int i = tid; i < TS; i += kBlock) d.gslab[(size_t)job * TS + i] = s_g[i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4b: one workgroup per stored tile of S: pose terms (H_pp diagonal blocks, odometry blocks) minus
+// the job slabs of this tile, summed in a fixed order.  Diagonal tiles also assemble their part of g.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_assemble(BaDev d)
+{
+    extern __shared__ __align__(16) double s_tile[]; // [TS*TS]
+    const int TS = d.TS, PB = TS / 6, n = 6 * d.Pf;
+    const int tile = blockIdx.x, tid = threadIdx.x;
+    const int ti = d.tile_ti[tile], tj = d.tile_tj[tile];
+    for (int i = tid; i < TS * TS; i += kBlock) s_tile[i] = 0.0;
+    __syncthreads();
+    if (d.add_pose_terms) {
+        if (ti == tj) {
+            for (int i = tid; i < PB * 36; i += kBlock) {
+                const int pl = i / 36, rr = (i % 36) / 6, cc = i % 6;
+                const int r = ti * PB + pl;
+                if (r < d.Pf) {
+                    const int a = rr < cc ? rr : cc, b = rr < cc ? cc : rr;
+                    s_tile[(pl * 6 + rr) * TS + pl * 6 + cc] = d.Hpp[(size_t)21 * r + (a * 6 - a * (a - 1) / 2) + (b - a)];
+                }
+            }
+        }
+        __syncthreads();
+        for (int q = d.tile_aux_ptr[tile] * 36 + tid; q < d.tile_aux_ptr[tile + 1] * 36; q += kBlock) {
+            const int ref = d.tile_aux_ref[q / 36], k = ref >> 1, tr = ref & 1;
+            const int rr = (q % 36) / 6, cc = q % 6;
+            const int ri = d.pose_red[d.se3_i[k]], rj = d.pose_red[d.se3_j[k]];
+            const int rhi = tr ? rj : ri, rlo = tr ? ri : rj; // row pose, column pose of the lower block
+            const double v = tr ? d.se3_out[(size_t)120 * k + 72 + 6 * cc + rr] : d.se3_out[(size_t)120 * k + 72 + 6 * rr + cc];
+            atomicAdd(&s_tile[((rhi % PB) * 6 + rr) * TS + (rlo % PB) * 6 + cc], v);
+        }
+    }
+    __syncthreads();
+    const int j0 = d.tile_job_ptr[tile], j1 = d.tile_job_ptr[tile + 1];
+    double* out = d.S + (size_t)tile * TS * TS;
+    for (int i = tid; i < TS * TS; i += kBlock) {
+        double v = s_tile[i];
+        for (int j = j0; j < j1; ++j) v -= d.slab[(size_t)d.tile_jobs[j] * TS * TS + i];
+        if (ti == tj) { // padding rows of the last tile: identity
+            const int rr = i / TS, cc = i % TS;
+            if (ti * TS + rr >= n || ti * TS + cc >= n) v = (rr == cc) ? 1.0 : 0.0;
+        }
+        out[i] = v;
+    }
+    if (ti == tj) {
+        for (int i = tid; i < TS; i += kBlock) {
+            const int row = ti * TS + i;
+            double v = 0.0;
+            if (row < n) {
+                if (d.add_pose_terms) v = d.bp[row];
+                for (int j = j0; j < j1; ++j) v -= d.gslab[(size_t)d.tile_jobs[j] * TS + i];
+            }
+            d.g[row] = v;
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K7 (poses): trial pose = pose [+] dx (g2o VertexSE3::oplusImpl); pose part of g2o's computeScale.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kBlock) void k_update_poses(BaDev d, int cur, double lambda)
+{
+    __shared__ double s_red[4];
+    const double* __restrict__ src = d.pose[cur];
+    double* __restrict__ dst = d.pose[cur ^ 1];
+    double part[1] = {0.0};
+    for (int s = threadIdx.x; s < d.Pn; s += kBlock) {
+        const int r = d.pose_red[s];
+        if (r < 0) {
+            for (int k = 0; k < 12; ++k) dst[12 * s + k] = src[12 * s + k];
+        } else {
+            double dl[6];
+            for (int k = 0; k < 6; ++k) { dl[k] = d.dx[6 * r + k]; part[0] += dl[k] * (lambda * dl[k] + d.bp[6 * r + k]); }
+            pose_oplus(src + 12 * s, dl, dst + 12 * s);
+        }
+    }
+    block_sum<1>(part, s_red);
+    if (threadIdx.x == 0) d.scal[3] = part[0];
+}
+
+// ---------------------------------------------------------------------------------------------
+// K6 + K7 (landmarks) + K8: back-substitution dl = Hinv (b_l - sum_a W_a' dx_a), trial landmark,
+// landmark part of computeScale, then the error sweep of the trial state.  Same workgroup shape as K2.
+// BACKSUB = false: plain chi2 sweep of state `cur`.
+// ---------------------------------------------------------------------------------------------
+template <bool BACKSUB>
+__global__ __launch_bounds__(kBlock) void k_backsub_chi2(BaDev d, int cur, double lambda)
+{
+    __shared__ double s_v[3][kLmBlockEdges];
+    __shared__ double s_lm[3][kLmBlockEdges];
+    __shared__ double s_red[3 * 4];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const int l0 = d.lb_lm[b], l1 = d.lb_lm[b + 1];
+    const int e0 = d.lm_ptr[l0], e1 = d.lm_ptr[l1];
+    const size_t E = d.E, Ll = d.Ll;
+    const int e = e0 + tid;
+    const int trial = BACKSUB ? (cur ^ 1) : cur;
+    const double* __restrict__ pose_t = d.pose[trial];
+    double part[3] = {0.0, 0.0, 0.0}; // robust chi2, plain chi2, scale
+    int s = 0;
+    if (e < e1) s = d.e_pose[e];
+    if (BACKSUB) {
+        if (e < e1) {
+            const int r = d.pose_red[s];
+            double v[3] = {0.0, 0.0, 0.0};
+            if (r >= 0) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) {
+                    const double dxi = d.dx[6 * r + i];
+#pragma unroll
+                    for (int c = 0; c < 3; ++c) v[c] += d.W[(size_t)(3 * i + c) * E + e] * dxi;
+                }
+            }
+            s_v[0][tid] = v[0]; s_v[1][tid] = v[1]; s_v[2][tid] = v[2];
+        }
+        __syncthreads();
+    }
+    const int l = l0 + tid;
+    if (l < l1) {
+        double pn[3];
+        const double* __restrict__ lm = d.lm[cur];
+        if (BACKSUB) {
+            double rhs[3] = {d.bl[l], d.bl[Ll + l], d.bl[2 * Ll + l]};
+            const double bb[3] = {rhs[0], rhs[1], rhs[2]};
+            for (int a = d.lm_ptr[l] - e0; a < d.lm_ptr[l + 1] - e0; ++a) { rhs[0] -= s_v[0][a]; rhs[1] -= s_v[1][a]; rhs[2] -= s_v[2][a]; }
+            double Hi[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) Hi[k] = d.Hinv[(size_t)k * Ll + l];
+            const double dl[3] = {Hi[0] * rhs[0] + Hi[1] * rhs[1] + Hi[2] * rhs[2], Hi[1] * rhs[0] + Hi[3] * rhs[1] + Hi[4] * rhs[2],
+                                  Hi[2] * rhs[0] + Hi[4] * rhs[1] + Hi[5] * rhs[2]};
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                pn[k] = lm[3 * l + k] + dl[k];
+                d.lm[cur ^ 1][3 * l + k] = pn[k];
+                part[2] += dl[k] * (lambda * dl[k] + bb[k]);
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pn[k] = lm[3 * l + k];
+        }
+        s_lm[0][tid] = pn[0]; s_lm[1][tid] = pn[1]; s_lm[2][tid] = pn[2];
+        for (int q = d.lm_ll_ptr[l]; q < d.lm_ll_ptr[l + 1]; ++q) {
+            double ee[3], O[6];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) ee[k] = pn[k] - d.ll_ref[3 * q + k] - d.ll_z[3 * q + k];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) O[k] = d.ll_info[6 * q + k];
+            const double c2 = ee[0] * (O[0] * ee[0] + 2.0 * (O[1] * ee[1] + O[2] * ee[2])) +
+                              ee[1] * (O[3] * ee[1] + 2.0 * O[4] * ee[2]) + ee[2] * O[5] * ee[2];
+            double w = 1.0, r0 = c2;
+            if (d.ll_robust[q]) cauchy(d.cauchy_delta, c2, r0, w);
+            part[0] += r0; part[1] += c2;
+        }
+    }
+    __syncthreads();
+    if (e < e1) {
+        EdgeIn in;
+        load_edge(d.e_z, d.e_info, d.info_planes, d.e_flags, (int)E, e, in);
+        const int ll = d.e_lm[e] - l0;
+        double R[9], t[3];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) R[k] = pose_t[12 * s + k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) t[k] = pose_t[12 * s + 9 + k];
+        const double p[3] = {s_lm[0][ll], s_lm[1][ll], s_lm[2][ll]};
+        double err[3];
+        proj_error(in.type, R, t, p, in.z, d.fx, d.fy, d.cx, d.cy, err);
+        const double c2 = edge_chi2(in, err);
+        double w = 1.0, r0 = c2;
+        if (in.robust) cauchy(d.cauchy_delta, c2, r0, w);
+        part[0] += r0; part[1] += c2;
+    }
+    block_sum<3>(part, s_red);
+    if (tid == 0) {
+        d.block_part[4 * b + 0] = part[0];
+        d.block_part[4 * b + 1] = part[1];
+        d.block_part[4 * b + 2] = part[2];
+    }
+}
+
+// scal[0] robust chi2, scal[1] plain chi2, scal[2] landmark part of the step scale (trial state)
+__global__ __launch_bounds__(kBlock) void k_reduce_trial(BaDev d)
+{
+    __shared__ double s_red[3 * 4];
+    double part[3] = {0.0, 0.0, 0.0};
+    for (int b = threadIdx.x; b < d.n_lm_blocks; b += kBlock) {
+        part[0] += d.block_part[4 * b];
+        part[1] += d.block_part[4 * b + 1];
+        part[2] += d.block_part[4 * b + 2];
+    }
+    block_sum<3>(part, s_red);
+    if (threadIdx.x == 0) {
+        d.scal[0] = part[0] + d.scal[6];
+        d.scal[1] = part[1] + d.scal[7];
+        d.scal[2] = part[2];
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_debug_jacobians(BaDev d, int cur, const int* __restrict__ e_orig, double* err,
+                                                            double* Jp, double* Jl)
+{
+    const int e = blockIdx.x * kBlock + threadIdx.x;
+    if (e >= d.E) return;
+    EdgeIn in;
+    load_edge(d.e_z, d.e_info, d.info_planes, d.e_flags, d.E, e, in);
+    const int s = d.e_pose[e], l = d.e_lm[e];
+    const double* pose = d.pose[cur];
+    const double* lm = d.lm[cur];
+    double ee[3], J[27];
+    proj_eval(in.type, pose + 12 * s, pose + 12 * s + 9, lm + 3 * l, in.z, d.fx, d.fy, d.cx, d.cy, ee, J);
+    const size_t o = e_orig[e];
+    for (int r = 0; r < 3; ++r) {
+        err[3 * o + r] = ee[r];
+        for (int c = 0; c < 6; ++c) Jp[18 * o + 6 * r + c] = J[9 * r + c];
+        for (int c = 0; c < 3; ++c) Jl[9 * o + 3 * r + c] = J[9 * r + 6 + c];
+    }
+}
+
+} // namespace
+
+// ---------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------
+static inline hipStream_t S_(void* st) { return static_cast<hipStream_t>(st); }
+
+void ba_linearize_lm(const BaDev& d, int cur, void* st)
+{
+    if (d.n_lm_blocks > 0) hipLaunchKernelGGL(k_linearize_lm, dim3(d.n_lm_blocks), dim3(kBlock), 0, S_(st), d, cur);
+}
+void ba_linearize_pose(const BaDev& d, int cur, void* st)
+{
+    if (d.n_chunks > 0) hipLaunchKernelGGL(k_linearize_pose, dim3(d.n_chunks), dim3(kBlock), 0, S_(st), d, cur);
+}
+void ba_linearize_aux(const BaDev& d, int cur, int, void* st)
+{
+    hipLaunchKernelGGL((k_aux_edges<true>), dim3(1), dim3(kBlock), 0, S_(st), d, cur);
+}
+void ba_chi2_aux(const BaDev& d, int which, int, void* st)
+{
+    hipLaunchKernelGGL((k_aux_edges<false>), dim3(1), dim3(kBlock), 0, S_(st), d, which);
+}
+void ba_pose_finalize(const BaDev& d, const int* red_slot, int rank, int n_ranks, void* st)
+{
+    if (d.Pf > 0) hipLaunchKernelGGL(k_pose_finalize, dim3((d.Pf * 27 + kBlock - 1) / kBlock), dim3(kBlock), 0, S_(st), d, red_slot);
+    hipLaunchKernelGGL(k_reduce_lin_scalars, dim3(1), dim3(kBlock), 0, S_(st), d, rank, n_ranks);
+}
+void ba_lin_post(const BaDev& d, int n_ranks, void* st)
+{
+    hipLaunchKernelGGL(k_lin_post, dim3(1), dim3(kBlock), 0, S_(st), d, n_ranks);
+}
+void ba_invert_landmarks(const BaDev& d, double lambda, void* st)
+{
+    if (d.Ll > 0) hipLaunchKernelGGL(k_invert_landmarks, dim3((d.Ll + kBlock - 1) / kBlock), dim3(kBlock), 0, S_(st), d, lambda);
+}
+void ba_schur(const BaDev& d, void* st)
+{
+    const size_t lds = sizeof(double) * ((size_t)d.TS * d.TS + d.TS);
+    if (d.n_jobs > 0) hipLaunchKernelGGL(k_schur, dim3(d.n_jobs), dim3(kBlock), lds, S_(st), d);
+}
+void ba_assemble(const BaDev& d, void* st)
+{
+    const size_t lds = sizeof(double) * (size_t)d.TS * d.TS;
+    if (d.n_tiles > 0) hipLaunchKernelGGL(k_assemble, dim3(d.n_tiles), dim3(kBlock), lds, S_(st), d);
+}
+void ba_update_poses(const BaDev& d, int cur, double lambda, void* st)
+{
+    hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(kBlock), 0, S_(st), d, cur, lambda);
+}
+void ba_backsub_chi2(const BaDev& d, int cur, double lambda, void* st)
+{
+    if (d.n_lm_blocks > 0) hipLaunchKernelGGL((k_backsub_chi2<true>), dim3(d.n_lm_blocks), dim3(kBlock), 0, S_(st), d, cur, lambda);
+}
+void ba_chi2_only(const BaDev& d, int which, void* st)
+{
+    if (d.n_lm_blocks > 0) hipLaunchKernelGGL((k_backsub_chi2<false>), dim3(d.n_lm_blocks), dim3(kBlock), 0, S_(st), d, which, 0.0);
+}
+void ba_reduce_trial_scalars(const BaDev& d, void* st)
+{
+    hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(kBlock), 0, S_(st), d);
+}
+void ba_debug_jacobians(const BaDev& d, int cur, const int* e_orig, double* err, double* Jp, double* Jl, void* st)
+{
+    if (d.E > 0) hipLaunchKernelGGL(k_debug_jacobians, dim3((d.E + kBlock - 1) / kBlock), dim3(kBlock), 0, S_(st), d, cur, e_orig, err, Jp, Jl);
+}
+
+// dynamic LDS above 64 KB has to be requested per kernel
+void ba_configure_kernels(int TS)
+{
+    const int lds = (int)(sizeof(double) * ((size_t)TS * TS + TS));
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+}
+
+} // namespace svi

@@ -1,0 +1,74 @@
+// common.h — status plumbing shared by the C-ABI translation units (host side only).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+
+#include "svi_hot.h"
+
+namespace svi {
+
+// Thread-local last-error text (svi_last_error()).
+inline std::string& last_error()
+{
+    static thread_local std::string e;
+    return e;
+}
+
+inline int fail(int status, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof(buf), fmt, ap);
+    va_end(ap);
+    last_error() = buf;
+    return status;
+}
+
+#define SVI_HIP(call)                                                                                   \
+    do {                                                                                                \
+        hipError_t e_ = (call);                                                                         \
+        if (e_ != hipSuccess)                                                                           \
+            return svi::fail(SVI_ERR_HIP, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+    } while (0)
+
+// Select `device`, verifying that one exists. The library has no CPU fallback: no device => error.
+inline int use_device(int device)
+{
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n <= 0) return fail(SVI_ERR_NO_DEVICE, "no HIP device visible (%s)", hipGetErrorString(e));
+    if (device < 0 || device >= n) return fail(SVI_ERR_INVALID, "device %d out of range (have %d)", device, n);
+    SVI_HIP(hipSetDevice(device));
+    return SVI_OK;
+}
+
+// Growable device buffer owned by a handle.
+struct DevBuf {
+    void*  p   = nullptr;
+    size_t cap = 0;
+    int reserve(size_t bytes)
+    {
+        if (bytes <= cap) return SVI_OK;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        size_t want = bytes + bytes / 4 + 256;
+        SVI_HIP(hipMalloc(&p, want));
+        cap = want;
+        return SVI_OK;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+    template <class T> T* as() const { return static_cast<T*>(p); }
+};
+
+} // namespace svi

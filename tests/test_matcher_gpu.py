@@ -1,0 +1,170 @@
+"""GPU parity of the Hamming matcher against the CPU oracle: bit-exact indices and distances."""
+import numpy as np
+import pytest
+
+from svi_mapper_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def matcher(svi):
+    m = svi.HammingMatcher(device=0)
+    yield m
+    m.close()
+
+
+def _rand_desc(rng, n):
+    return rng.integers(0, 256, (n, 32), dtype=np.uint8)
+
+
+@pytest.mark.parametrize("nq,nt", [(1, 1), (1, 300), (64, 64), (257, 1023), (2048, 2048), (3, 5000), (1000, 1)])
+def test_ungated_matches_oracle(matcher, oracle, nq, nt):
+    rng = np.random.default_rng(nq * 7919 + nt)
+    q, t = _rand_desc(rng, nq), _rand_desc(rng, nt)
+    # force ties: duplicate a few pool rows
+    if nt > 8:
+        t[nt // 2] = t[1]
+        t[nt - 1] = t[3]
+    idx, dist = matcher.match_arrays(q, t)
+    ridx, rdist = oracle.match_hamming256(q, t)
+    np.testing.assert_array_equal(idx, ridx)
+    np.testing.assert_array_equal(dist, rdist)
+
+
+def test_c2_gated_bit_exact(matcher, oracle):
+    c2 = synth.make_descriptor_pair()
+    idx, dist = matcher.match_arrays(c2["q"], c2["t"], c2["gate"], c2["cutoff"])
+    ridx, rdist = oracle.match_hamming256(c2["q"], c2["t"], c2["gate"], c2["cutoff"])
+    np.testing.assert_array_equal(idx, ridx)
+    np.testing.assert_array_equal(dist, rdist)
+    # the generator plants true matches: most of them must be recovered
+    planted = c2["truth"] >= 0
+    assert (idx[planted] == c2["truth"][planted]).mean() > 0.9
+    assert (idx < 0).sum() > 0  # and some queries have no candidate under the gate
+
+
+def test_ties_pick_lowest_index(matcher):
+    rng = np.random.default_rng(5)
+    q = _rand_desc(rng, 70)
+    t = np.repeat(q[:1], 900, axis=0)  # every pool row identical: all distances tie
+    idx, dist = matcher.match_arrays(q, t)
+    assert (idx == 0).all()
+    t2 = _rand_desc(rng, 900)
+    t2[[17, 400, 899]] = q[5]
+    idx, dist = matcher.match_arrays(q, t2)
+    assert idx[5] == 17 and dist[5] == 0
+
+
+def test_cutoff_is_strict(matcher):
+    q = np.zeros((1, 32), np.uint8)
+    t = np.zeros((2, 32), np.uint8)
+    t[0, :13] = 0xFF  # distance 104
+    t[1, :12] = 0xFF
+    t[1, 12] = 0x0F   # distance 100
+    idx, dist = matcher.match_arrays(q, t, None, 100)
+    assert idx[0] == -1 and dist[0] == 257  # 100 is not < 100 (CTriangulator.cpp:107)
+    idx, dist = matcher.match_arrays(q, t, None, 101)
+    assert idx[0] == 1 and dist[0] == 100
+
+
+def test_empty_pool_and_empty_gate(matcher):
+    rng = np.random.default_rng(1)
+    q = _rand_desc(rng, 10)
+    idx, dist = matcher.match_arrays(q, np.zeros((0, 32), np.uint8))
+    assert (idx == -1).all() and (dist == 257).all()
+    assert matcher.match(q, np.zeros((0, 32), np.uint8)) == []
+    t = _rand_desc(rng, 50)
+    gate = dict(q_uv=np.zeros((10, 2), np.float32), t_uv=np.ones((50, 2), np.float32) * 5,
+                q_umin=np.zeros(10, np.float32), q_umax=np.ones(10, np.float32), v_tol=0.0)
+    idx, dist = matcher.match_arrays(q, t, gate)
+    assert (idx == -1).all()
+
+
+def test_dmatch_shape(matcher):
+    rng = np.random.default_rng(2)
+    q, t = _rand_desc(rng, 4), _rand_desc(rng, 9)
+    ms = matcher.match(q, t)
+    assert [m.queryIdx for m in ms] == [0, 1, 2, 3]
+    for m in ms:
+        d = np.unpackbits(q[m.queryIdx] ^ t[m.trainIdx]).sum()
+        assert m.distance == float(d) and m.imgIdx == 0
+
+
+def test_pairs_and_triangulation(matcher, oracle):
+    rng = np.random.default_rng(3)
+    a, b = _rand_desc(rng, 1000), _rand_desc(rng, 1000)
+    np.testing.assert_array_equal(matcher.norm_hamming(a, b), oracle.hamming256_pairs(a, b))
+    cam = synth.kitti_camera()
+    uvL = np.stack([rng.uniform(100, 1200, 500), rng.integers(28, 340, 500)], 1).astype(np.float32)
+    d = rng.uniform(-1, 150, 500).astype(np.float32)
+    d[:5] = [0.0, 0.009, 0.01, 0.0100001, 1.0]
+    uvR = uvL.copy()
+    uvR[:, 0] = uvL[:, 0] - d
+    xyz, ok = matcher.triangulate(cam["fx"], cam["cx"], cam["cy"], cam["duR_flipped"], uvL, uvR)
+    rxyz, rok = oracle.triangulate_rectified(cam["fx"], cam["cx"], cam["cy"], cam["duR_flipped"], uvL, uvR)
+    np.testing.assert_array_equal(ok, rok)
+    np.testing.assert_array_equal(xyz, rxyz)  # bit-exact f64
+    assert ok.sum() < 500 and ok.sum() > 400
+
+
+def test_batched_device_and_fused(matcher, oracle):
+    import torch
+    B, nq, nt = 5, 333, 777
+    rng = np.random.default_rng(11)
+    cam = synth.kitti_camera()
+    sets = [synth.make_descriptor_pair(nq, nt, seed=100 + b) for b in range(B)]
+    dev = torch.device("cuda:0")
+    cat = lambda k: torch.from_numpy(np.concatenate([s[k] for s in sets])).to(dev)  # noqa: E731
+    catg = lambda k: torch.from_numpy(np.concatenate([s["gate"][k] for s in sets])).to(dev)  # noqa: E731
+    q, t = cat("q"), cat("t")
+    gate = dict(q_uv=catg("q_uv"), t_uv=catg("t_uv"), q_umin=catg("q_umin"), q_umax=catg("q_umax"), v_tol=0.0)
+    idx = torch.empty(B * nq, dtype=torch.int32, device=dev)
+    dist = torch.empty_like(idx)
+    xyz = torch.empty(B * nq, 3, dtype=torch.float64, device=dev)
+    ok = torch.empty(B * nq, dtype=torch.uint8, device=dev)
+    torch.cuda.synchronize()
+    matcher.match_triangulate_dev(q, t, nq, nt, B, gate, 100, cam["fx"], cam["cx"], cam["cy"], cam["duR_flipped"],
+                                  idx, dist, xyz, ok)
+    matcher.synchronize()
+    idx, dist, xyz, ok = idx.cpu().numpy(), dist.cpu().numpy(), xyz.cpu().numpy(), ok.cpu().numpy()
+    for b, s in enumerate(sets):
+        ridx, rdist = oracle.match_hamming256(s["q"], s["t"], s["gate"], 100)
+        sl = slice(b * nq, (b + 1) * nq)
+        np.testing.assert_array_equal(idx[sl], ridx)
+        np.testing.assert_array_equal(dist[sl], rdist)
+        hit = ridx >= 0
+        uvR = s["gate"]["t_uv"][np.maximum(ridx, 0)]
+        rxyz, rok = oracle.triangulate_rectified(cam["fx"], cam["cx"], cam["cy"], cam["duR_flipped"], s["gate"]["q_uv"], uvR)
+        np.testing.assert_array_equal(ok[sl][hit], rok[hit])
+        np.testing.assert_array_equal(xyz[sl][hit], rxyz[hit])
+        assert (ok[sl][~hit] == 0).all()
+
+
+def test_split_pool_path(matcher, oracle):
+    """Few queries, large ungated pool: the pool is split over workgroups and merged by atomicMin."""
+    rng = np.random.default_rng(21)
+    q, t = _rand_desc(rng, 100), _rand_desc(rng, 40000)
+    t[39999] = q[7]
+    t[123] = q[7]
+    idx, dist = matcher.match_arrays(q, t)
+    ridx, rdist = oracle.match_hamming256(q, t)
+    np.testing.assert_array_equal(idx, ridx)
+    np.testing.assert_array_equal(dist, rdist)
+    assert idx[7] == 123
+
+
+def test_triangulator_mirror(svi, matcher):
+    cam = synth.kitti_camera()
+    tri = svi.Triangulator(cam["fx"], cam["cx"], cam["cy"], -cam["duR_flipped"], cam["width"], matcher=matcher)
+    rng = np.random.default_rng(4)
+    pool = _rand_desc(rng, 80)
+    ref = pool[33].copy()
+    ref[0] ^= 1
+    xyz, uvR, desc = tri.get_point_triangulated_in_right(pool, 300.0, 100.0, 7.0, np.array([420.0, 128.0], np.float32), ref)
+    assert uvR[0] == np.float32(28 + 33 + 300) and uvR[1] == np.float32(128)
+    assert np.isclose(xyz[2], cam["duR_flipped"] / (420.0 - uvR[0]))
+    with pytest.raises(svi.NoMatchFound):
+        tri.get_point_triangulated_in_right(pool, 300.0, 100.0, 7.0, np.array([320.0, 128.0], np.float32), ref)
+    with pytest.raises(svi.NoMatchFound):
+        tri.get_point_in_left(np.array([10.0, 5.0]), np.array([10.0, 5.0]))
