@@ -1,0 +1,268 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path on MI355X (contract: see the task brief / DESIGN.md).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+Primary metric   LM-BA iterations/sec on the BASELINE config-4 graph (500 keyframes x 100 k landmarks x
+                 800 k edges, KITTI-00-shaped, synthetic), state resident in HBM; a "step" is one LM
+                 iteration (linearise + damped trial(s)) of the reference's schedule.
+                 N > 1: weak scaling - every rank owns a config-4-sized landmark shard of a graph with
+                 N x 100 k landmarks / N x 800 k edges over the same 500 keyframes; the reduced camera
+                 system is summed with one RCCL all-reduce per trial. value = N x iterations/sec
+                 (shard-iterations per second over the whole job).
+Secondary        stereo desc-pairs/sec on config 2 (2 x 2048 BRIEF-256, epipolar-gated), in "matcher".
+roofline         the Jacobian sweep (K2 + K3), algorithmic bytes 328 E + 96 P + 24 L over
+                 its mean duration measured with HIP events on the library's stream.
+cpu_baseline     the CPU oracle (oracle/, a restatement of the g2o/CHOLMOD path, 1 thread) on a bounded
+                 sample of the same workload, rank 0 at N = 1 only.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+FP64_MFMA_PEAK_TF = 78.6   # SURVEY.md §8d (FP64 vector/matrix)
+
+
+def cached_problem(scale):
+    """config 4 (x landmark scale), cached under /tmp because the numpy generator takes ~40 s."""
+    from svi_mapper_amd import synth
+    path = "/tmp/svi_c4_scale%d_v2.npz" % scale
+    keys = ("R_true", "t_true", "R_init", "t_init", "lm_true", "lm_init", "obs_kf", "obs_lm", "uvL", "uvR", "xyz")
+    if os.path.exists(path):
+        try:
+            z = np.load(path)
+            prob = {k: z[k] for k in keys}
+            prob.update(cam=synth.kitti_camera(), n_kf=int(z["n_kf"]), n_lm=int(z["n_lm"]))
+            return prob
+        except Exception:
+            pass
+    prob = synth.make_c4(landmark_scale=scale)
+    try:
+        tmp = path + ".%d.tmp.npz" % os.getpid()
+        np.savez(tmp, n_kf=prob["n_kf"], n_lm=prob["n_lm"], **{k: prob[k] for k in keys})
+        os.replace(tmp, path)
+    except Exception:
+        pass
+    return prob
+
+
+def run_exact(ba, n):
+    """exactly n LM iterations (a block that terminates early is followed by a fresh block, like the
+    reference's while loop would)"""
+    done = 0
+    while done < n:
+        r = ba.optimize(n - done)
+        if r <= 0:
+            raise RuntimeError("optimize performed no iteration")
+        done += r
+    return done
+
+
+def bench_matcher(svi, steps=1000, warmup=50):
+    import torch
+    from svi_mapper_amd import synth
+    dev = torch.device("cuda", torch.cuda.current_device())
+    c2 = synth.make_descriptor_pair()
+    nq, nt = len(c2["q"]), len(c2["t"])
+    st = torch.cuda.Stream()
+    m = svi.HammingMatcher(device=dev.index, stream=st.cuda_stream)
+    out = {}
+
+    def timed(batch, gated, n, w):
+        rep = lambda a: torch.from_numpy(np.tile(a, (batch,) + (1,) * (a.ndim - 1))).to(dev)  # noqa: E731
+        q, t = rep(c2["q"]), rep(c2["t"])
+        gate = None
+        if gated:
+            g = c2["gate"]
+            gate = dict(q_uv=rep(g["q_uv"]), t_uv=rep(g["t_uv"]), q_umin=rep(g["q_umin"]), q_umax=rep(g["q_umax"]), v_tol=0.0)
+        idx = torch.empty(batch * nq, dtype=torch.int32, device=dev)
+        dist = torch.empty_like(idx)
+        torch.cuda.synchronize()
+        for _ in range(w):
+            m.match_dev(q, t, nq, nt, batch, idx, dist, gate, c2["cutoff"] if gated else 257)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        st.synchronize()
+        e0.record(st)
+        for _ in range(n):
+            m.match_dev(q, t, nq, nt, batch, idx, dist, gate, c2["cutoff"] if gated else 257)
+        e1.record(st)
+        e1.synchronize()
+        ms = e0.elapsed_time(e1) / n
+        return ms, float(batch) * nq * nt / (ms * 1e-3)
+
+    ms, rate = timed(1, True, steps, warmup)
+    out["gated_single"] = {"ms_per_call": ms, "pairs_per_s": rate}
+    ms, rate = timed(64, True, max(steps // 10, 20), 5)
+    out["gated_batch64"] = {"ms_per_call": ms, "pairs_per_s": rate}
+    ms, rate = timed(1, False, steps, warmup)
+    out["ungated_single"] = {"ms_per_call": ms, "pairs_per_s": rate}
+    ms, rate = timed(64, False, max(steps // 10, 20), 5)
+    out["ungated_batch64"] = {"ms_per_call": ms, "pairs_per_s": rate}
+    # 180 224 algorithmic bytes per call, 17 integer lane-ops per pair
+    alg_bytes = 32 * (nq + nt) + 8 * (nq + nt) + 8 * nq
+    b = out["ungated_batch64"]
+    out["roofline"] = {"bound": "valu-int", "algorithmic_bytes_per_pair_set": alg_bytes,
+                       "hbm_GBps_batch64": 64 * alg_bytes / (b["ms_per_call"] * 1e-3) / 1e9,
+                       "lane_ops_per_s_batch64": 17.0 * b["pairs_per_s"]}
+    m.close()
+    return {"metric": "stereo desc-pairs/sec", "workload": "config 2: 2x2048 BRIEF-256, epipolar-gated, KITTI-00 camera",
+            "value": out["gated_single"]["pairs_per_s"], "unit": "pairs/s", "dtype": "u8", **out}
+
+
+def cpu_baseline(prob, iters):
+    """The CPU oracle (restatement of the g2o/CHOLMOD path), 1 thread, -O3 -march=native, timed on this host."""
+    from oracle import oracle as orc
+    from svi_mapper_amd import synth
+    lib = None
+    try:
+        lib = orc.load(orc.build(native=True))
+    except Exception:
+        lib = orc.load()
+    cam = prob["cam"]
+    o = orc.OracleBA(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"], lib=lib)
+    synth.build_ba_graph(o, prob)
+    o.initialize()
+    t0 = time.time()
+    done = 0
+    while done < iters:
+        done += o.optimize(iters - done)
+    dt = time.time() - t0
+    model = ""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    return {"value": done / dt, "unit": "LM iterations/s", "cores": 1, "kind": "port",
+            "sample": "first %d LM iterations of the same config-4 graph (%d edges), CPU restatement of the g2o/CHOLMOD path "
+                      "(full-system sparse LL', no Schur), gcc -O3 -march=native, %.1f s" % (done, o.num_edges, dt),
+            "host_cpu": model, "host_cores_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-matcher", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--chol-tile", type=int, default=96)
+    ap.add_argument("--backend", default="nccl")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import svi_mapper_amd as svi
+    from svi_mapper_amd import dist as sdist
+    from svi_mapper_amd import synth
+
+    rank, world, local = sdist.init_from_env(args.backend)
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    torch.cuda.set_device(local)
+    prob = cached_problem(world)
+    cam = prob["cam"]
+
+    def make(profile):
+        ba = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"], device=local, rank=rank,
+                                n_ranks=world, profile=profile, chol_tile=args.chol_tile)
+        stored = synth.build_ba_graph(ba, prob)
+        if world > 1:
+            ba.set_allreduce(sdist.make_allreduce_hook())
+        ba.initialize()
+        return ba, stored
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- timed run -------------------------------------------------------------------------------
+    ba, stored = make(False)
+    run_exact(ba, args.warmup)
+    s0 = ba.stats()
+    barrier()
+    t0 = time.perf_counter()
+    run_exact(ba, args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    s1 = ba.stats()
+    trials = (s1.lm_trials - s0.lm_trials) / max(1, s1.lm_iterations - s0.lm_iterations)
+    chi_plain, chi_robust = ba.chi2()
+    ba.close()
+
+    # ---- profiled run: per-phase device time from HIP events on the library's stream -----------------
+    bap, _ = make(True)
+    run_exact(bap, args.warmup)
+    bap.reset_phase_times()
+    run_exact(bap, args.steps)
+    phases = bap.phase_times()
+    st = bap.stats()
+    bap.close()
+
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+    E, P, L = int(st.n_edges_proj_local), int(st.n_poses), int(st.n_landmarks_local)
+    sweep_bytes = 328 * E + 96 * P + 24 * L
+    ms_lm, n_lm = phases["linearize_lm"]
+    ms_pose, n_pose = phases["linearize_pose"]
+    sweep_ms = (ms_lm / max(n_lm, 1)) + (ms_pose / max(n_pose, 1))
+    achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+    ms_chol, n_chol = phases["cholesky"]
+    chol_ms = ms_chol / max(n_chol, 1)
+    pmc = None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("sweep_hbm_bytes_per_launch")
+    except Exception:
+        pass
+    line = {
+        "metric": "LM-BA iterations/sec", "value": world * args.steps / dt, "unit": "iterations/s", "n_gpus": world,
+        "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "config 4: KITTI-00-shaped BA, 500 keyframes x %d landmarks x %d projection edges "
+                               "(xyz %d / uv-depth %d / uv-disparity %d) + 499 odometry + 500 gravity edges; "
+                               "%d-way landmark-sharded, reference LM schedule" % (int(st.n_landmarks), int(st.n_edges_proj), stored[0], stored[1], stored[2], world),
+                   "keyframes": P, "landmarks_per_gpu": L, "edges_per_gpu": E, "parallelism": "landmark-shard x%d" % world,
+                   "chol_tile": int(st.chol_tile), "reduced_n": int(st.chol_n), "reduced_tiles": int(st.chol_tiles_nnz),
+                   "trials_per_iteration": trials, "final_chi2_plain": chi_plain, "final_chi2_robust": chi_robust,
+                   "allreduce_doubles_per_trial": int(st.reduce_doubles) if world > 1 else 0},
+        "roofline": {"bound": "hbm", "kernel": "Jacobian sweep = k_linearize_lm + k_linearize_pose", "achieved": achieved,
+                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc,
+                     "algorithmic_bytes": sweep_bytes, "avg_ms": sweep_ms},
+        "roofline_cholesky": {"bound": "mfma", "kernel": "tile-sparse LL' (potrf+trsm+gemm+solve)", "achieved": st.chol_flops / (chol_ms * 1e-3) / 1e12 if chol_ms > 0 else 0.0,
+                              "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "flops": st.chol_flops, "avg_ms": chol_ms},
+        "phases_ms_per_call": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in phases.items()},
+        "phases_calls": {k: v[1] for k, v in phases.items()},
+    }
+    line["roofline_cholesky"]["frac"] = line["roofline_cholesky"]["achieved"] / FP64_MFMA_PEAK_TF
+    if world == 1 and not args.no_matcher:
+        line["matcher"] = bench_matcher(svi)
+    if world == 1 and not args.no_cpu_baseline:
+        line["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters)
+        line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
+    print(json.dumps(line))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

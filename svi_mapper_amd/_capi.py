@@ -111,6 +111,34 @@ SIGNATURES = {
 }
 
 _lib = None
+_hip = None
+
+
+def _preload_hip_runtime():
+    """libsvi_hot.so has no DT_NEEDED on the HIP runtime; bind it to the one this process uses.
+    PyTorch-ROCm bundles its own libamdhip64 / libhsa-runtime64, and two copies in one process cannot
+    both drive the GPU, so torch's copy wins whenever torch is importable; otherwise $ROCM_PATH's."""
+    global _hip
+    if _hip is not None:
+        return _hip
+    cands = []
+    try:
+        import torch  # noqa: F401  (also makes sure torch's runtime is the first one loaded)
+        cands.append(os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so"))
+    except Exception:
+        pass
+    rocm = os.environ.get("ROCM_PATH", "/opt/rocm")
+    cands += [os.path.join(rocm, "lib", "libamdhip64.so"), "libamdhip64.so"]
+    err = None
+    for c in cands:
+        if os.path.sep in c and not os.path.exists(c):
+            continue
+        try:
+            _hip = C.CDLL(c, mode=C.RTLD_GLOBAL)
+            return _hip
+        except OSError as e:
+            err = e
+    raise ImportError("svi_mapper_amd: no HIP runtime (libamdhip64) could be loaded: %s" % err)
 
 
 def load_library(path=None):
@@ -122,6 +150,7 @@ def load_library(path=None):
     if not os.path.exists(p):
         raise ImportError("svi_mapper_amd: %s not found - build it with `python -c 'import __graft_entry__ as g; "
                           "g.build()'` or `make -C svi_mapper_amd/csrc` (hipcc, gfx950). There is no CPU fallback." % p)
+    _preload_hip_runtime()
     lib = C.CDLL(p)
     missing = []
     for name, (res, args) in SIGNATURES.items():

@@ -1,0 +1,75 @@
+"""Multi-GPU plumbing for the landmark-sharded BA: one process per GPU,
+torch.distributed over RCCL (backend "nccl" on ROCm) carrying the one exchange step of the path —
+the sum of the reduced camera normal equations — through the C ABI's all-reduce hook.
+
+The library calls the hook with a device pointer, a count of doubles and the HIP stream it is
+working on; the hook wraps the pointer as a torch tensor (no copy) and issues dist.all_reduce with
+that stream current, so the collective is stream-ordered between the Schur kernels before it and the
+Cholesky after it without any host synchronisation.
+"""
+import numpy as np
+
+
+def landmark_shards(edge_lm_slot, n_landmarks, n_ranks):
+    """Contiguous landmark-slot ranges balanced by projection-edge count: the partition the library
+    applies internally (ba_host.cpp build_structure). Returns bounds[n_ranks + 1]."""
+    deg = np.zeros(n_landmarks + 1, np.int64)
+    np.add.at(deg, np.asarray(edge_lm_slot, np.int64) + 1, 1)
+    cum = np.cumsum(deg)
+    total = int(cum[-1])
+    bounds = [0]
+    for r in range(1, n_ranks):
+        bounds.append(int(min(max(np.searchsorted(cum, total * r // n_ranks, side="left"), 0), n_landmarks)))
+    bounds.append(n_landmarks)
+    return np.asarray(bounds, np.int64)
+
+
+class _DevPtr:
+    """Minimal __cuda_array_interface__ carrier so torch can alias library-owned HBM."""
+
+    def __init__(self, ptr, count):
+        self.__cuda_array_interface__ = {"shape": (int(count),), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def make_allreduce_hook(group=None):
+    """Returns fn(ptr, count, stream) for BundleAdjuster.set_allreduce, summing over `group`."""
+    import torch
+    import torch.distributed as dist
+
+    cache = {}
+
+    def hook(ptr, count, stream):
+        key = (ptr, count)
+        t = cache.get(key)
+        if t is None:
+            t = torch.as_tensor(_DevPtr(ptr, count), device=torch.device("cuda", torch.cuda.current_device()))
+            cache[key] = t
+        ext = torch.cuda.ExternalStream(stream)
+        with torch.cuda.stream(ext):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        return 0
+
+    return hook
+
+
+def init_from_env(backend="nccl"):
+    """torchrun-style init: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment."""
+    import os
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", str(rank)))
+    if backend == "nccl":
+        torch.cuda.set_device(local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        kw = {}
+        if backend == "nccl":
+            kw["device_id"] = torch.device("cuda", local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world, **kw)
+    return rank, world, local

