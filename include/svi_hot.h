@@ -293,6 +293,12 @@ int svi_ba_debug_edge_jacobians(svi_ba* ba, double* err /*E x 3*/, double* J_pos
 int svi_ba_debug_reduced_system(svi_ba* ba, double lambda, double* S, double* g, int64_t cap,
                                 int64_t* n_out);
 
+/* timing probe of the diagonal-tile Cholesky kernel (tile 48 or 96): mean ms per launch over `reps`
+ * launches, truncated after phase `stop_after` (0 full, 1 pivot sweep, 2 +scale/store, 3 +diagonal
+ * block inverses, 4 +off-diagonal inverse blocks, 5 load only; 6: ms[0] = shader cycles and ms[1] = 100 MHz
+ * ticks spent in the pivot sweep, ms must have room for 2 doubles) */
+int svi_debug_chol_probe(int device, int tile, int reps, int stop_after, double* ms);
+
 #ifdef __cplusplus
 }
 #endif

@@ -4,16 +4,22 @@
 // src/optimization/Cg2oOptimizer.cpp:83) on the pose part of the system once the landmarks have
 // been eliminated (their elimination is the Schur reduction of ba_kernels.hip).  S is stored as
 // TS x TS tiles of its lower block triangle, only tiles that can be non-zero after fill-in; the
-// factorisation is right-looking over tile columns:
-//     potrf:  L_kk = chol(S_kk + lambda I) and L_kk^-1            one workgroup, LDS resident
-//     trsm :  L_ik = S_ik L_kk^-T  as a GEMM with L_kk^-1           one workgroup per tile, FP64 MFMA
-//     gemm :  S_ij -= L_ik L_jk'                                    one workgroup per tile, FP64 MFMA
-// (v_mfma_f64_16x16x4_f64; this dense block is the only MFMA-shaped work on the whole path).
+// factorisation is right-looking over tile columns k:
+//   potrf : L_kk = chol(S_kk + lambda I), L_kk^-1, y_k = L_kk^-1 g_k      one workgroup
+//           (register-resident right-looking sweep, one barrier per column; the inverse is built
+//            from 16x16 blocks with FP64 MFMA)
+//   trsm  : L_ik = S_ik L_kk^-T as a GEMM with L_kk^-1                     one workgroup per 48x48 block, FP64 MFMA
+//   gemm  : S_ij -= L_ik L_jk' ;  g_i -= L_ik y_k                          one workgroup per 48x48 block, FP64 MFMA
+// so the forward substitution rides along with the factorisation; the backward substitution is one
+// workgroup walking the tile columns in reverse.  v_mfma_f64_16x16x4_f64 on this dense block is the
+// only MFMA-shaped work on the whole path.  L goes to a separate tile array (trsm is then free of
+// read/write races between the workgroups sharing a tile).
 // A non-positive pivot sets *status = k+1: the caller treats the LM trial as failed, like g2o does
 // when CHOLMOD reports "not positive definite".
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <vector>
 
 #include "ba_device.h"
 
@@ -21,247 +27,516 @@ namespace svi {
 namespace {
 
 constexpr int kBlock = 256;
+constexpr int kOB = 48; // output block edge of the trsm / gemm workgroups
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
-__device__ __forceinline__ int ldp(int TS) { return TS + 2; } // LDS row stride: (TS+2) % 32 == 2 -> conflict-free b64 reads
+template <int TS> struct Lds { static constexpr int LD = TS + 2; }; // (TS+2) % 32 == 2: conflict-free ds_read_b64 of MFMA operands
 
-// copy a TS x TS row-major tile global -> LDS (padded rows)
-__device__ __forceinline__ void tile_to_lds(const double* __restrict__ g, double* s, int TS)
+// rows [r0, r0+NR) of a TS x TS row-major global tile -> LDS (row stride LD)
+template <int TS, int NR>
+__device__ __forceinline__ void rows_to_lds(const double* __restrict__ g, int r0, double* s)
 {
-    const int LD = ldp(TS);
-    for (int i = threadIdx.x; i < TS * TS / 2; i += kBlock) {
-        const int r = (2 * i) / TS, c = (2 * i) % TS;
-        const double2 v = *reinterpret_cast<const double2*>(g + 2 * i);
-        s[r * LD + c] = v.x;
-        s[r * LD + c + 1] = v.y;
+    constexpr int LD = Lds<TS>::LD;
+    const double2* src = reinterpret_cast<const double2*>(g + (size_t)r0 * TS);
+    constexpr int N = NR * TS / 2, IT = (N + kBlock - 1) / kBlock;
+    double2 v[IT];
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int i = it * kBlock + threadIdx.x;
+        if (N % kBlock == 0 || i < N) v[it] = src[i];
+    }
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+        const int i = it * kBlock + threadIdx.x;
+        if (N % kBlock == 0 || i < N) {
+            const int r = i / (TS / 2), c = 2 * (i % (TS / 2));
+            s[r * LD + c] = v[it].x;
+            s[r * LD + c + 1] = v[it].y;
+        }
     }
 }
 
-// ---------------------------------------------------------------------------------------------
-// potrf + triangular inverse of one diagonal tile
-// ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_potrf_inv(double* tiles, double* Linv, int tile_id, int k, int TS, int n,
-                                                      double lambda, int* status)
-{
-    extern __shared__ __align__(16) double sm[];
-    const int LD = ldp(TS);
-    double* sA = sm;           // [TS][LD]
-    double* sX = sm + TS * LD; // [TS][LD]
-    __shared__ int s_fail;
-    const int tid = threadIdx.x;
-    if (*status != 0) return;
-    double* A = tiles + (size_t)tile_id * TS * TS;
-    tile_to_lds(A, sA, TS);
-    if (tid == 0) s_fail = 0;
-    __syncthreads();
-    if (tid < TS && k * TS + tid < n) sA[tid * LD + tid] += lambda; // g2o setLambda: H_jj += lambda on real rows
-    __syncthreads();
-
-    // Right-looking LDL-style sweep with ONE barrier per column: at step j every thread applies
-    // A[r][c] -= A[r][j] A[c][j] / A[j][j] to its elements of the trailing lower triangle; column j
-    // itself is left unscaled and scaled by 1/sqrt(A[j][j]) at the end.
-    for (int j = 0; j < TS; ++j) {
-        const double djj = sA[j * LD + j];
-        if (!(djj > 0.0)) { if (tid == 0) s_fail = 1; break; } // uniform: every thread reads the same value
-        const double rinv = 1.0 / djj;
-        const int m = TS - j - 1; // trailing size
-        // elements (r,c), j < c <= r < TS, enumerated row-major over the m x m lower triangle
-        const int cnt = m * (m + 1) / 2;
-        for (int q = tid; q < cnt; q += kBlock) {
-            int rr = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
-            while ((rr + 1) * (rr + 2) / 2 <= q) ++rr;
-            while (rr * (rr + 1) / 2 > q) --rr;
-            const int cc = q - rr * (rr + 1) / 2;
-            const int r = j + 1 + rr, c = j + 1 + cc;
-            sA[r * LD + c] -= sA[r * LD + j] * sA[c * LD + j] * rinv;
-        }
-        __syncthreads();
-    }
-    __syncthreads();
-    if (s_fail) { if (tid == 0) *status = k + 1; return; }
-    // scale columns: L[r][j] = A[r][j] / sqrt(A[j][j])
-    for (int q = tid; q < TS * TS; q += kBlock) {
-        const int r = q / TS, j = q % TS;
-        if (j <= r) {
-            const double s = 1.0 / sqrt(sA[j * LD + j]);
-            sX[r * LD + j] = sA[r * LD + j] * s; // stage in sX to avoid racing on the diagonal
-        }
-    }
-    __syncthreads();
-    for (int q = tid; q < TS * TS; q += kBlock) {
-        const int r = q / TS, j = q % TS;
-        const double v = (j <= r) ? sX[r * LD + j] : 0.0;
-        sA[r * LD + j] = v;
-        A[q] = v; // L_kk with an explicit zero upper triangle
-    }
-    __syncthreads();
-    // X = L^-1, one column per thread (forward substitution on e_j)
-    if (tid < TS) {
-        const int j = tid;
-        for (int i = 0; i < j; ++i) sX[i * LD + j] = 0.0;
-        sX[j * LD + j] = 1.0 / sA[j * LD + j];
-        for (int i = j + 1; i < TS; ++i) {
-            double acc = 0.0;
-            for (int m = j; m < i; ++m) acc += sA[i * LD + m] * sX[m * LD + j];
-            sX[i * LD + j] = -acc / sA[i * LD + i];
-        }
-    }
-    __syncthreads();
-    double* X = Linv + (size_t)k * TS * TS;
-    for (int q = tid; q < TS * TS; q += kBlock) X[q] = sX[(q / TS) * LD + (q % TS)];
-}
-
-// one 16x16 sub-tile of C = A B' with A, B in LDS (row-major, stride LD), K = TS
-__device__ __forceinline__ v4f64 mfma_subtile(const double* sA, const double* sB, int r0, int c0, int TS, int LD)
+// 16x16 block of C = A B' (A: rows ra.., B: rows rb.. of LDS images with stride LD), K = KK
+template <int KK, int LD>
+__device__ __forceinline__ v4f64 mfma_block(const double* sA, int ra, const double* sB, int rb)
 {
     const int lane = threadIdx.x & 63;
-    const double* pa = sA + (r0 + (lane & 15)) * LD + (lane >> 4);
-    const double* pb = sB + (c0 + (lane & 15)) * LD + (lane >> 4);
+    const double* pa = sA + (ra + (lane & 15)) * LD + (lane >> 4);
+    const double* pb = sB + (rb + (lane & 15)) * LD + (lane >> 4);
+    double a[KK / 4], b[KK / 4];
+#pragma unroll
+    for (int q = 0; q < KK / 4; ++q) { a[q] = pa[4 * q]; b[q] = pb[4 * q]; }
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll 4
-    for (int kk = 0; kk < TS; kk += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[kk], pb[kk], acc, 0, 0, 0);
+#pragma unroll
+    for (int q = 0; q < KK / 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
     return acc;
 }
 
-// trsm: tile (i,k) <- tile(i,k) * Linv_kk'
-__global__ __launch_bounds__(kBlock) void k_trsm(double* tiles, const double* __restrict__ Linv, const int* __restrict__ list,
-                                                 int k, int TS, const int* status)
+// 1/x to full double precision from the hardware seed (two Newton steps), no IEEE division sequence
+__device__ __forceinline__ double fast_rcp(double x)
 {
-    extern __shared__ __align__(16) double sm[];
-    if (*status != 0) return;
-    const int LD = ldp(TS);
-    double* sA = sm;
-    double* sB = sm + TS * LD;
-    double* A = tiles + (size_t)list[blockIdx.x] * TS * TS;
-    tile_to_lds(A, sA, TS);
-    tile_to_lds(Linv + (size_t)k * TS * TS, sB, TS);
-    __syncthreads();
-    const int nsub = TS / 16, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int st = wave; st < nsub * nsub; st += 4) {
-        const int r0 = (st / nsub) * 16, c0 = (st % nsub) * 16;
-        const v4f64 acc = mfma_subtile(sA, sB, r0, c0, TS, LD);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) A[(size_t)(r0 + (lane >> 4) + 4 * q) * TS + c0 + (lane & 15)] = acc[q];
-    }
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(r, fma(-x, r, 1.0), r);
+    r = fma(r, fma(-x, r, 1.0), r);
+    return r;
 }
-
-// update: tile c -= tile a * tile b'
-__global__ __launch_bounds__(kBlock) void k_gemm_upd(double* tiles, const int* __restrict__ ua, const int* __restrict__ ub,
-                                                     const int* __restrict__ uc, int TS, const int* status)
+// 1/sqrt(x) to full double precision
+__device__ __forceinline__ double fast_rsqrt(double x)
 {
-    extern __shared__ __align__(16) double sm[];
-    if (*status != 0) return;
-    const int LD = ldp(TS);
-    double* sA = sm;
-    double* sB = sm + TS * LD;
-    const int ia = ua[blockIdx.x], ib = ub[blockIdx.x];
-    tile_to_lds(tiles + (size_t)ia * TS * TS, sA, TS);
-    if (ib != ia) tile_to_lds(tiles + (size_t)ib * TS * TS, sB, TS);
-    else sB = sA;
-    __syncthreads();
-    double* C = tiles + (size_t)uc[blockIdx.x] * TS * TS;
-    const int nsub = TS / 16, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int st = wave; st < nsub * nsub; st += 4) {
-        const int r0 = (st / nsub) * 16, c0 = (st % nsub) * 16;
-        const v4f64 acc = mfma_subtile(sA, sB, r0, c0, TS, LD);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) C[(size_t)(r0 + (lane >> 4) + 4 * q) * TS + c0 + (lane & 15)] -= acc[q];
-    }
+    double r = __builtin_amdgcn_rsq(x);
+    // r <- r + r*(1 - x r^2)/2, twice
+    r = fma(r * 0.5, fma(-x * r, r, 1.0), r);
+    r = fma(r * 0.5, fma(-x * r, r, 1.0), r);
+    return r;
 }
 
 // ---------------------------------------------------------------------------------------------
-// triangular solves L y = g, L' x = y over the tile structure (one workgroup; vectors in global)
+// potrf + inverse + y_k of one diagonal tile, 512 threads (two waves per SIMD: one wave alone issues
+// an FP64 op only every 8 cycles).  The 16x16 blocks (a,b), b <= a, of the lower triangle are split
+// between the two halves of the workgroup by the parity of a; thread (ty,tx) of half H keeps
+// A[16a+ty][16b+tx] in registers for the whole factorisation.  The right-looking sweep eliminates
+// FOUR columns per barrier: the 4x4 pivot block is factorised redundantly by every lane.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_chol_solve(const double* __restrict__ tiles, const double* __restrict__ Linv,
-                                                       const double* __restrict__ g, double* x, CholPlan p, const int* status)
+constexpr int kPotrfThreads = 512;
+
+template <int TS, int H>
+__device__ __forceinline__ bool potrf_sweep(const double* __restrict__ A, double* __restrict__ Lg, double* sL, double* sX,
+                                            double (*s_col)[4][TS], double* s_rs, int k, int n, double lambda, int stop_after,
+                                            double* __restrict__ y)
 {
-    __shared__ double s_acc[kMaxTile];
-    __shared__ double s_part[4][kMaxTile];
-    const int TS = p.TS, NT = p.NT, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (*status != 0) return;
-    // forward: y_k = Linv_kk (g_k - sum_{j<k} L_kj y_j); y stored in x
-    for (int k = 0; k < NT; ++k) {
-        if (tid < TS) s_acc[tid] = g[k * TS + tid];
-        __syncthreads();
-        for (int q = p.row_ptr[k]; q < p.row_ptr[k + 1]; ++q) {
-            const double* L = tiles + (size_t)p.row_tile[q] * TS * TS;
-            const double* y = x + p.row_col[q] * TS;
-            for (int r = wave; r < TS; r += 4) {
-                double s = 0.0;
-                for (int c = lane; c < TS; c += 64) s += L[r * TS + c] * y[c];
+    constexpr int NB = TS / 16, LD = Lds<TS>::LD, KB = 4;
+    constexpr int NI = (NB - H + 1) / 2; // blocks rows a = H, H+2, ... owned by this half
+    const int tid = threadIdx.x, ty = (tid >> 4) & 15, tx = tid & 15;
+    double e[NI > 0 ? NI : 1][NB];
 #pragma unroll
-                for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-                if (lane == 0) s_acc[r] -= s;
-            }
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int b = 0; b <= 2 * i + H; ++b) {
+            const int r = 16 * (2 * i + H) + ty, c = 16 * b + tx;
+            double v = A[r * TS + c];
+            if (r == c && k * TS + r < n) v += lambda; // g2o setLambda: H_jj += lambda on real rows
+            e[i][b] = v;
+        }
+    if (stop_after == 5) { if (tid < TS) y[k * TS + tid] = e[0][0]; return true; }
+    long long t_clk0 = 0, t_rt0 = 0;
+    const int probe = (stop_after >= 6 && stop_after <= 9) ? stop_after : 0;
+    if (probe) { t_clk0 = clock64(); t_rt0 = wall_clock64(); }
+    bool fail = false;
+#pragma unroll
+    for (int jb = 0; jb < NB; ++jb) {
+        constexpr int dummy = 0; (void)dummy;
+        // first owned block row with a >= jb
+        const int i0 = (jb <= H) ? 0 : (jb - H + 1) / 2;
+        for (int jq = 0; jq < 16 / KB; ++jq) {
+            const int jx = KB * jq, j = 16 * jb + jx;
+            double (*col)[TS] = s_col[jq & 1];
+#pragma unroll
+            for (int m = 0; m < KB; ++m)
+                if (tx == jx + m) {
+#pragma unroll
+                    for (int i = 0; i < NI; ++i)
+                        if (i >= i0) col[m][16 * (2 * i + H) + ty] = e[i][jb];
+                }
             __syncthreads();
-        }
-        const double* X = Linv + (size_t)k * TS * TS;
-        for (int r = wave; r < TS; r += 4) {
-            double s = 0.0;
-            for (int c = lane; c <= r; c += 64) s += X[r * TS + c] * s_acc[c];
+            if (probe == 9) continue;
+            // KB x KB pivot block, LDL' in registers (every lane redundantly)
+            double w[KB][KB], l[KB][KB], rinv[KB];
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
-            if (lane == 0) x[k * TS + r] = s;
+            for (int m = 0; m < KB; ++m) {
+#pragma unroll
+                for (int q = 0; q <= m; ++q) {
+                    double v = col[q][j + m];
+#pragma unroll
+                    for (int t = 0; t < q; ++t) v = fma(-w[m][t], l[q][t], v);
+                    w[m][q] = v;
+                    if (q < m) l[m][q] = v * rinv[q];
+                }
+                const double dm = w[m][m];
+                if (!(dm > 0.0)) fail = true; // uniform: every lane sees the same pivot block
+                rinv[m] = fast_rcp(dm);
+                if (tid == 0) s_rs[j + m] = dm;
+            }
+            if (fail) break;
+            if (probe == 8) { if (rinv[3] == 12345.0) e[0][0] += rinv[0]; continue; }
+            // eliminated panel entries of the owned rows (scaled by 1/d) and of the columns
+            double ur[KB][NI > 0 ? NI : 1], uc[KB][NB];
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (i >= i0) {
+                    double wr[KB];
+#pragma unroll
+                    for (int q = 0; q < KB; ++q) {
+                        double vr = col[q][16 * (2 * i + H) + ty];
+#pragma unroll
+                        for (int t = 0; t < q; ++t) vr = fma(-wr[t], l[q][t], vr);
+                        wr[q] = vr;
+                        ur[q][i] = vr * rinv[q];
+                    }
+                }
+#pragma unroll
+            for (int b = jb; b < NB; ++b) {
+                double wc[KB];
+#pragma unroll
+                for (int q = 0; q < KB; ++q) {
+                    double vc = col[q][16 * b + tx];
+#pragma unroll
+                    for (int t = 0; t < q; ++t) vc = fma(-wc[t], l[q][t], vc);
+                    wc[q] = vc;
+                    uc[q][b] = vc;
+                }
+            }
+            if (probe == 7) { if (ur[0][0] + uc[3][NB - 1] == 12345.0) e[0][0] += 1.0; continue; }
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+                if (i >= i0) {
+#pragma unroll
+                    for (int b = jb; b <= 2 * i + H; ++b) {
+                        // element (16a+ty, 16b+tx): pivot column j+q applies to columns c > j+q
+                        double v = e[i][b];
+#pragma unroll
+                        for (int q = 0; q < KB; ++q)
+                            if (b > jb || tx > jx + q) v = fma(-ur[q][i], uc[q][b], v);
+                        e[i][b] = v;
+                    }
+                }
         }
-        __syncthreads();
-        __threadfence_block();
+        if (fail) break;
     }
-    // backward: x_k = Linv_kk' (y_k - sum_{i>k} L_ik' x_i)
+    __syncthreads();
+    if (fail) return false;
+    if (probe) { // shader cycles and 100 MHz ticks spent in the pivot sweep
+        if (tid == 0) { y[0] = (double)(clock64() - t_clk0); y[1] = (double)(wall_clock64() - t_rt0); y[2] = e[0][0]; }
+        return true;
+    }
+    if (stop_after == 1) { if (tid < TS) y[k * TS + tid] = e[0][0]; return true; }
+    if (tid < TS) s_rs[tid] = fast_rsqrt(s_rs[tid]);
+    __syncthreads();
+    // L[r][c] = A[r][c] / sqrt(d_c) -> LDS image (zero upper triangle), zeroed X, global L tile
+#pragma unroll
+    for (int i = 0; i < NI; ++i)
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int r = 16 * (2 * i + H) + ty, c = 16 * b + tx;
+            double v = 0.0;
+            if (b <= 2 * i + H && c <= r) v = e[i][b <= 2 * i + H ? b : 0] * s_rs[c];
+            sL[r * LD + c] = v;
+            sX[r * LD + c] = 0.0;
+            Lg[r * TS + c] = v;
+        }
+    return true;
+}
+
+template <int TS>
+__global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(const double* __restrict__ S, double* __restrict__ Lt, double* __restrict__ Linv,
+                                                             const double* __restrict__ g, double* __restrict__ y, int tile_id, int k, int n,
+                                                             double lambda, int* status, int stop_after)
+{
+    constexpr int NB = TS / 16, LD = Lds<TS>::LD;
+    extern __shared__ __align__(16) double sm[];
+    double* sL = sm;            // [TS][LD]
+    double* sX = sm + TS * LD;  // [TS][LD]
+    // one scratch block serves the pivot sweep (published columns, [parity][column of the quad][row])
+    // and later the inverse (per-wave 16x16 staging): the two never overlap in time
+    constexpr int kScratch = (2 * 4 * TS > (NB - 1) * 256) ? 2 * 4 * TS : (NB - 1) * 256;
+    __shared__ double s_buf[kScratch];
+    __shared__ double s_rs[TS];        // 1/sqrt(d_j) = 1/L_jj
+    __shared__ double s_g[TS];
+    static_assert(sizeof(double) * (2 * TS * LD + kScratch + 2 * TS) <= 160 * 1024, "potrf LDS budget (160 KiB per workgroup)");
+    double (*s_col)[4][TS] = reinterpret_cast<double (*)[4][TS]>(s_buf);
+    double (*s_T)[16 * 16] = reinterpret_cast<double (*)[16 * 16]>(s_buf);
+    const int tid = threadIdx.x;
+    if (*status != 0) return;
+    const double* A = S + (size_t)tile_id * TS * TS;
+    double* Lg = Lt + (size_t)tile_id * TS * TS;
+    if (tid < TS) s_g[tid] = g[k * TS + tid];
+    const int half = __builtin_amdgcn_readfirstlane(tid >> 8); // wave-uniform
+    bool ok;
+    if (half == 0) ok = potrf_sweep<TS, 0>(A, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y);
+    else           ok = potrf_sweep<TS, 1>(A, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y);
+    if (!ok) { if (tid == 0) *status = k + 1; return; }
+    if (stop_after == 5 || (stop_after >= 6 && stop_after <= 9) || stop_after == 1) return;
+    __syncthreads();
+    if (stop_after == 2) return;
+    // ---- X = L^-1 ----
+    // (1) inverses of the 16x16 diagonal blocks: thread (block i0, column q) forward-substitutes e_q with
+    //     its column in registers (static indexing), 1/L_rr taken from the factorisation
+    if (tid < TS) {
+        const int i0 = (tid >> 4) * 16, q = tid & 15;
+        double x[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            double acc = (r == q) ? 1.0 : 0.0;
+#pragma unroll
+            for (int m = 0; m < r; ++m) acc = fma(-sL[(i0 + r) * LD + i0 + m], x[m], acc);
+            x[r] = (r >= q) ? acc * s_rs[i0 + r] : 0.0;
+        }
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sX[(i0 + r) * LD + i0 + q] = x[r];
+    }
+    __syncthreads();
+    if (stop_after == 3) return;
+    // (2) off-diagonal blocks, one block column per wave: X_ij = -X_ii * sum_{m=j}^{i-1} L_im X_mj
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        double* sT = s_T[wave];
+        for (int j = wave; j < NB - 1; j += kPotrfThreads / 64) {
+            for (int i = j + 1; i < NB; ++i) {
+                v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+                for (int m = j; m < i; ++m) {
+                    const double* pa = sL + (16 * i + (lane & 15)) * LD + 16 * m + (lane >> 4);
+                    const double* pb = sX + (16 * m + (lane >> 4)) * LD + 16 * j + (lane & 15);
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) { av[q] = pa[4 * q]; bv[q] = pb[4 * q * LD]; }
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sT[((lane >> 4) + 4 * q) * 16 + (lane & 15)] = acc[q];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+                v4f64 r = {0.0, 0.0, 0.0, 0.0};
+                const double* pd = sX + (16 * i + (lane & 15)) * LD + 16 * i + (lane >> 4);
+                const double* pt = sT + (lane >> 4) * 16 + (lane & 15);
+                double dv[4], tv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { dv[q] = pd[4 * q]; tv[q] = pt[4 * q * 16]; }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) r = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[q], tv[q], r, 0, 0, 0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sX[(16 * i + (lane >> 4) + 4 * q) * LD + 16 * j + (lane & 15)] = -r[q];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                __builtin_amdgcn_wave_barrier();
+            }
+        }
+    }
+    __syncthreads();
+    if (stop_after == 4) return;
+    {
+        double* X = Linv + (size_t)k * TS * TS;
+#pragma unroll
+        for (int it = 0; it < (TS * TS + kPotrfThreads - 1) / kPotrfThreads; ++it) {
+            const int q = it * kPotrfThreads + tid;
+            if ((TS * TS) % kPotrfThreads == 0 || q < TS * TS) X[q] = sX[(q / TS) * LD + (q % TS)];
+        }
+    }
+    // y_k = L_kk^-1 g_k (g_k is final: every earlier column has already subtracted its part)
+    if (tid < TS) {
+        double acc = 0.0;
+#pragma unroll 8
+        for (int c = 0; c < TS; ++c) acc = fma(sX[tid * LD + c], s_g[c], acc); // X is zero above the diagonal
+        y[k * TS + tid] = acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// trsm: L(i,k)[block] = S(i,k)[rows] * Linv_kk[cols]'      grid: (#tiles * (TS/48)^2)
+// ---------------------------------------------------------------------------------------------
+template <int TS>
+__global__ __launch_bounds__(kBlock) void k_trsm(const double* __restrict__ S, double* __restrict__ Lt, const double* __restrict__ Linv,
+                                                 const int* __restrict__ list, int k, const int* status)
+{
+    constexpr int LD = Lds<TS>::LD, Q = TS / kOB;
+    extern __shared__ __align__(16) double sm[];
+    if (*status != 0) return;
+    double* sA = sm;
+    double* sB = sm + kOB * LD;
+    const int t = list[blockIdx.x / (Q * Q)], qq = blockIdx.x % (Q * Q), qr = qq / Q, qc = qq % Q;
+    rows_to_lds<TS, kOB>(S + (size_t)t * TS * TS, kOB * qr, sA);
+    rows_to_lds<TS, kOB>(Linv + (size_t)k * TS * TS, kOB * qc, sB);
+    __syncthreads();
+    double* out = Lt + (size_t)t * TS * TS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int st = wave; st < 9; st += 4) {
+        const int r0 = (st / 3) * 16, c0 = (st % 3) * 16;
+        const v4f64 acc = mfma_block<TS, LD>(sA, r0, sB, c0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) out[(size_t)(kOB * qr + r0 + (lane >> 4) + 4 * q) * TS + kOB * qc + c0 + (lane & 15)] = acc[q];
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// update: S(c)[block] -= L(a)[rows] L(b)[cols]' ; diagonal targets also carry g_i -= L_ik y_k
+// ---------------------------------------------------------------------------------------------
+template <int TS>
+__global__ __launch_bounds__(kBlock) void k_gemm_upd(double* __restrict__ S, const double* __restrict__ Lt, const int* __restrict__ ua,
+                                                     const int* __restrict__ ub, const int* __restrict__ uc, const int* __restrict__ urow,
+                                                     int k, double* __restrict__ g, const double* __restrict__ y, const int* status)
+{
+    constexpr int LD = Lds<TS>::LD, Q = TS / kOB;
+    extern __shared__ __align__(16) double sm[];
+    if (*status != 0) return;
+    double* sA = sm;
+    double* sB = sm + kOB * LD;
+    const int u = blockIdx.x / (Q * Q), qq = blockIdx.x % (Q * Q), qr = qq / Q, qc = qq % Q;
+    const int ia = ua[u], ib = ub[u];
+    rows_to_lds<TS, kOB>(Lt + (size_t)ia * TS * TS, kOB * qr, sA);
+    rows_to_lds<TS, kOB>(Lt + (size_t)ib * TS * TS, kOB * qc, sB);
+    __syncthreads();
+    double* C = S + (size_t)uc[u] * TS * TS;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int st = wave; st < 9; st += 4) {
+        const int r0 = (st / 3) * 16, c0 = (st % 3) * 16;
+        const v4f64 acc = mfma_block<TS, LD>(sA, r0, sB, c0);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) C[(size_t)(kOB * qr + r0 + (lane >> 4) + 4 * q) * TS + kOB * qc + c0 + (lane & 15)] -= acc[q];
+    }
+    if (ia == ib && qc == 0 && threadIdx.x < kOB) { // forward substitution rides along: g_i -= L_ik y_k
+        const int r = threadIdx.x;
+        double acc = 0.0;
+        for (int m = 0; m < TS; ++m) acc += sA[r * LD + m] * y[k * TS + m];
+        g[urow[u] * TS + kOB * qr + r] -= acc;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// backward substitution x_k = Linv_kk' (y_k - sum_{i>k} L_ik' x_i), one workgroup, x in place of y.
+// Thread (c, part) owns column c and a slice of the rows of each tile: all its loads of a tile are
+// issued together (constant trip count), partial sums meet in LDS.
+// ---------------------------------------------------------------------------------------------
+template <int TS>
+__global__ __launch_bounds__(kBlock) void k_back_solve(const double* __restrict__ Lt, const double* __restrict__ Linv, double* x, CholPlan p,
+                                                       const int* status)
+{
+    constexpr int RP = kBlock / TS, RN = (TS + RP - 1) / RP; // row parts per column, rows per part
+    __shared__ double s_acc[TS];
+    __shared__ double s_xi[TS];
+    __shared__ double s_part[RP][TS];
+    const int NT = p.NT, tid = threadIdx.x;
+    const int c = tid % TS, part = tid / TS;
+    const bool active = part < RP;
+    const int r0 = part * RN;
+    if (*status != 0) return;
     for (int k = NT - 1; k >= 0; --k) {
         if (tid < TS) s_acc[tid] = x[k * TS + tid];
-        __syncthreads();
         for (int q = p.col_ptr[k]; q < p.col_ptr[k + 1]; ++q) {
-            const double* L = tiles + (size_t)p.trsm_tile[q] * TS * TS;
-            const double* xi = x + p.trsm_row[q] * TS;
-            for (int c = lane; c < TS; c += 64) {
+            const double* L = Lt + (size_t)p.trsm_tile[q] * TS * TS;
+            double v[RN];
+            if (active) {
+#pragma unroll
+                for (int i = 0; i < RN; ++i) v[i] = (r0 + i < TS) ? L[(r0 + i) * TS + c] : 0.0;
+            }
+            if (tid < TS) s_xi[tid] = x[p.trsm_row[q] * TS + tid];
+            __syncthreads();
+            if (active) {
                 double s = 0.0;
-                for (int r = wave; r < TS; r += 4) s += L[r * TS + c] * xi[r];
-                s_part[wave][c] = s;
+#pragma unroll
+                for (int i = 0; i < RN; ++i) s = fma(v[i], (r0 + i < TS) ? s_xi[r0 + i] : 0.0, s);
+                s_part[part][c] = s;
             }
             __syncthreads();
-            if (tid < TS) s_acc[tid] -= (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]);
-            __syncthreads();
+            if (tid < TS) {
+                double s = 0.0;
+#pragma unroll
+                for (int q2 = 0; q2 < RP; ++q2) s += s_part[q2][tid];
+                s_acc[tid] -= s;
+            }
         }
         const double* X = Linv + (size_t)k * TS * TS;
-        for (int c = lane; c < TS; c += 64) {
-            double s = 0.0;
-            for (int r = wave; r < TS; r += 4)
-                if (r >= c) s += X[r * TS + c] * s_acc[r];
-            s_part[wave][c] = s;
+        double v[RN];
+        if (active) {
+#pragma unroll
+            for (int i = 0; i < RN; ++i) v[i] = (r0 + i < TS && r0 + i >= c) ? X[(r0 + i) * TS + c] : 0.0;
         }
         __syncthreads();
-        if (tid < TS) x[k * TS + tid] = (s_part[0][tid] + s_part[1][tid]) + (s_part[2][tid] + s_part[3][tid]);
+        if (active) {
+            double s = 0.0;
+#pragma unroll
+            for (int i = 0; i < RN; ++i) s = fma(v[i], (r0 + i < TS) ? s_acc[r0 + i] : 0.0, s);
+            s_part[part][c] = s;
+        }
         __syncthreads();
-        __threadfence_block();
+        if (tid < TS) {
+            double s = 0.0;
+#pragma unroll
+            for (int q2 = 0; q2 < RP; ++q2) s += s_part[q2][tid];
+            x[k * TS + tid] = s;
+        }
+        __syncthreads();
     }
 }
 
-bool g_attr_done = false;
+template <int TS>
+int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n, int* status, hipStream_t s)
+{
+    constexpr int LD = Lds<TS>::LD, Q = TS / kOB;
+    const size_t lds_p = sizeof(double) * 2 * (size_t)TS * LD;
+    const size_t lds_g = sizeof(double) * 2 * (size_t)kOB * LD;
+    static bool attr = false;
+    if (!attr) {
+        // a workgroup asking for more LDS than the CU has faults the queue: refuse instead of launching
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv<TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm<TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_upd<TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g) != hipSuccess)
+            return 1;
+        attr = true;
+    }
+    for (int k = 0; k < p.NT; ++k) {
+        hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(1), dim3(kPotrfThreads), lds_p, s, S, Lt, Linv, g, x, p.h_diag_tile[k], k, n, lambda, status, 0);
+        const int nt = p.h_col_ptr[k + 1] - p.h_col_ptr[k];
+        if (nt > 0) hipLaunchKernelGGL(k_trsm<TS>, dim3(nt * Q * Q), dim3(kBlock), lds_g, s, S, Lt, Linv, p.trsm_tile + p.h_col_ptr[k], k, status);
+        const int nu = p.h_upd_ptr[k + 1] - p.h_upd_ptr[k];
+        if (nu > 0)
+            hipLaunchKernelGGL(k_gemm_upd<TS>, dim3(nu * Q * Q), dim3(kBlock), lds_g, s, S, Lt, p.upd_a + p.h_upd_ptr[k], p.upd_b + p.h_upd_ptr[k],
+                               p.upd_c + p.h_upd_ptr[k], p.upd_row + p.h_upd_ptr[k], k, g, x, status);
+    }
+    hipLaunchKernelGGL(k_back_solve<TS>, dim3(1), dim3(kBlock), 0, s, Lt, Linv, x, p, status);
+    return 0;
+}
 
 } // namespace
 
-void chol_factor_solve(const CholPlan& p, double* tiles, double* Linv, const double* g, double* x, double lambda, int n,
-                       int* status, void* st)
+// timing probe for the diagonal-tile kernel: reps launches on one SPD tile, truncated after phase
+// `stop_after` (0 = full kernel); returns the mean kernel time in ms
+template <int TS>
+static int potrf_probe(int reps, int stop_after, double* ms_out)
+{
+    constexpr int LD = Lds<TS>::LD;
+    const size_t lds_p = sizeof(double) * 2 * (size_t)TS * LD;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv<TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p) != hipSuccess) return 1;
+    double *S = nullptr, *L = nullptr, *X = nullptr, *g = nullptr, *y = nullptr;
+    int* st = nullptr;
+    std::vector<double> h((size_t)TS * TS);
+    for (int r = 0; r < TS; ++r)
+        for (int c = 0; c < TS; ++c) h[(size_t)r * TS + c] = (r == c ? TS + 1.0 : 0.0) + 1.0 / (1.0 + r + c);
+    if (hipMalloc(&S, sizeof(double) * TS * TS) != hipSuccess) return 1;
+    (void)hipMalloc(&L, sizeof(double) * TS * TS); (void)hipMalloc(&X, sizeof(double) * TS * TS);
+    (void)hipMalloc(&g, sizeof(double) * TS); (void)hipMalloc(&y, sizeof(double) * TS); (void)hipMalloc(&st, sizeof(int));
+    (void)hipMemcpy(S, h.data(), sizeof(double) * TS * TS, hipMemcpyHostToDevice);
+    (void)hipMemset(g, 0, sizeof(double) * TS); (void)hipMemset(st, 0, sizeof(int));
+    hipEvent_t a, b;
+    (void)hipEventCreate(&a); (void)hipEventCreate(&b);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(1), dim3(kPotrfThreads), lds_p, 0, S, L, X, g, y, 0, 0, TS, 0.0, st, stop_after);
+    (void)hipEventRecord(a, 0);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(1), dim3(kPotrfThreads), lds_p, 0, S, L, X, g, y, 0, 0, TS, 0.0, st, stop_after);
+    (void)hipEventRecord(b, 0);
+    (void)hipEventSynchronize(b);
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, a, b);
+    *ms_out = ms / reps;
+    if (stop_after >= 6 && stop_after <= 9) {
+        double hy[2] = {0, 0};
+        (void)hipMemcpy(hy, y, sizeof(hy), hipMemcpyDeviceToHost);
+        *ms_out = hy[0] * 1e-6 + hy[1] * 1e3; // packed: cycles*1e-6 + ticks*1e3 (decoded by tools/probe_chol.py)
+        ms_out[0] = hy[0]; // cycles
+        // ticks go to the second slot if the caller provided room
+        ms_out[1] = hy[1];
+    }
+    (void)hipFree(S); (void)hipFree(L); (void)hipFree(X); (void)hipFree(g); (void)hipFree(y); (void)hipFree(st);
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    return 0;
+}
+int chol_potrf_probe(int tile, int reps, int stop_after, double* ms)
+{
+    return tile == 48 ? potrf_probe<48>(reps, stop_after, ms) : potrf_probe<96>(reps, stop_after, ms);
+}
+
+// S (tiles) is consumed, L goes to Lt; g is consumed; x receives the solution
+int chol_factor_solve(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n, int* status,
+                      void* st)
 {
     hipStream_t s = static_cast<hipStream_t>(st);
-    const int TS = p.TS, LD = TS + 2;
-    const size_t lds2 = sizeof(double) * 2 * (size_t)TS * LD;
-    if (!g_attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 64);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_upd), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        g_attr_done = true;
-    }
-    for (int k = 0; k < p.NT; ++k) {
-        hipLaunchKernelGGL(k_potrf_inv, dim3(1), dim3(kBlock), lds2, s, tiles, Linv, p.h_diag_tile[k], k, TS, n, lambda, status);
-        const int nt = p.h_col_ptr[k + 1] - p.h_col_ptr[k];
-        if (nt > 0) hipLaunchKernelGGL(k_trsm, dim3(nt), dim3(kBlock), lds2, s, tiles, Linv, p.trsm_tile + p.h_col_ptr[k], k, TS, status);
-        const int nu = p.h_upd_ptr[k + 1] - p.h_upd_ptr[k];
-        if (nu > 0)
-            hipLaunchKernelGGL(k_gemm_upd, dim3(nu), dim3(kBlock), lds2, s, tiles, p.upd_a + p.h_upd_ptr[k], p.upd_b + p.h_upd_ptr[k],
-                               p.upd_c + p.h_upd_ptr[k], TS, status);
-    }
-    hipLaunchKernelGGL(k_chol_solve, dim3(1), dim3(kBlock), 0, s, tiles, Linv, g, x, p, status);
+    return p.TS == 48 ? run<48>(p, S, Lt, Linv, g, x, lambda, n, status, s) : run<96>(p, S, Lt, Linv, g, x, lambda, n, status, s);
 }
 
 } // namespace svi

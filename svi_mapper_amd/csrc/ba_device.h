@@ -101,6 +101,7 @@ struct BaDev {
     double* S;             // red_buf: [n_tiles][TS*TS] | g[NT*TS]   (one all-reduce per trial)
     double* g;             // = S + n_tiles*TS*TS
     int     red_count;
+    double* Lt;            // [n_tiles][TS*TS] Cholesky factor tiles
     double* Linv;          // [NT][TS*TS] inverses of the diagonal Cholesky factors
     double* dx;            // [NT*TS] solution (pose increments)
     int*    chol_status;   // [1] 0 ok, k+1: pivot failure in tile column k
@@ -143,6 +144,7 @@ struct CholPlan {
     const int* upd_a = nullptr;     // tile (i,k)
     const int* upd_b = nullptr;     // tile (j,k)
     const int* upd_c = nullptr;     // tile (i,j)
+    const int* upd_row = nullptr;   // tile row i of the target (g_i rides along on diagonal targets)
     // host copies of the counts
     const int* h_col_ptr = nullptr;
     const int* h_upd_ptr = nullptr;

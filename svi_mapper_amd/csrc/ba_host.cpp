@@ -39,8 +39,9 @@ void ba_chi2_only(const BaDev& d, int which, void* st);
 void ba_reduce_trial_scalars(const BaDev& d, void* st);
 void ba_debug_jacobians(const BaDev& d, int cur, const int* e_orig, double* err, double* Jp, double* Jl, void* st);
 void ba_configure_kernels(int TS);
-void chol_factor_solve(const CholPlan& p, double* tiles, double* Linv, const double* g, double* x, double lambda, int n,
-                       int* status, void* st);
+int chol_potrf_probe(int tile, int reps, int stop_after, double* ms);
+int chol_factor_solve(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n,
+                      int* status, void* st);
 
 void PhaseTimer::begin(int phase, hipStream_t s)
 {
@@ -528,6 +529,7 @@ int build_structure(svi_ba* ba)
     d.red_count = n_tiles * TS * TS + NT * TS;
     SVI_TRY(dev_alloc(ba, (size_t)d.red_count, &d.S));
     d.g = d.S + (size_t)n_tiles * TS * TS;
+    SVI_TRY(dev_alloc(ba, (size_t)n_tiles * TS * TS, &d.Lt));
     SVI_TRY(dev_alloc(ba, (size_t)NT * TS * TS, &d.Linv));
     SVI_TRY(dev_alloc(ba, (size_t)NT * TS, &d.dx));
     SVI_TRY(dev_alloc(ba, 1, &d.chol_status));
@@ -565,6 +567,7 @@ int build_structure(svi_ba* ba)
     SVI_TRY(dev_upload(ba, upd_a, &p.upd_a));
     SVI_TRY(dev_upload(ba, upd_b, &p.upd_b));
     SVI_TRY(dev_upload(ba, upd_c, &p.upd_c));
+    SVI_TRY(dev_upload(ba, upd_i, &p.upd_row));
     SVI_TRY(dev_upload(ba, diag_tile, &p.diag_tile));
     SVI_TRY(dev_upload(ba, row_ptr, &p.row_ptr));
     SVI_TRY(dev_upload(ba, row_tile, &p.row_tile));
@@ -636,7 +639,8 @@ int trial(svi_ba* ba, double lambda, bool* failed)
     SVI_HIP(hipGetLastError());
     SVI_TRY(allreduce(ba, d.S, (size_t)d.red_count));
     t.begin(SVI_PH_CHOLESKY, s);
-    if (d.NT > 0) chol_factor_solve(ba->plan, d.S, d.Linv, d.g, d.dx, lambda, 6 * d.Pf, d.chol_status, s);
+    if (d.NT > 0 && chol_factor_solve(ba->plan, d.S, d.Lt, d.Linv, d.g, d.dx, lambda, 6 * d.Pf, d.chol_status, s) != 0)
+        return fail(SVI_ERR_HIP, "Cholesky kernels could not be configured (LDS request refused)");
     t.end(s);
     t.begin(SVI_PH_BACKSUB_UPDATE, s);
     ba_update_poses(d, ba->cur, lambda, s);
@@ -1156,6 +1160,18 @@ int svi_ba_debug_edge_jacobians(svi_ba* ba, double* err, double* J_pose, double*
     (void)hipFree(de);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess)
         return fail(SVI_ERR_HIP, "debug_edge_jacobians: HIP failure");
+    return SVI_OK;
+}
+
+int svi_debug_chol_probe(int device, int tile, int reps, int stop_after, double* ms)
+{
+    if (!ms || reps < 1 || (tile != 48 && tile != 96)) return fail(SVI_ERR_INVALID, "bad probe argument");
+    if (int rc = use_device(device)) return rc;
+    double out[2] = {0, 0};
+    if (chol_potrf_probe(tile, reps, stop_after, out)) return fail(SVI_ERR_HIP, "probe failed");
+    // stop_after == 6: shader cycles of the pivot sweep in ms[0] and 100 MHz ticks in ms[1] (caller passes room for 2)
+    ms[0] = out[0];
+    if (stop_after >= 6 && stop_after <= 9) ms[1] = out[1];
     return SVI_OK;
 }
 
