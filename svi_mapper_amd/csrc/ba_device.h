@@ -106,27 +106,20 @@ struct BaDev {
     double* dx;            // [NT*TS] solution (pose increments)
     int*    chol_status;   // [1] 0 ok, k+1: pivot failure in tile column k
 
-    // Schur jobs
-    int n_items, n_jobs;
-    const int* it_lm;      // [n_items]
-    const int* it_a0;      // first lm-major edge of the row segment
-    const int* it_na;
-    const int* it_b0;      // first edge of the column segment (== it_a0 for diagonal tiles)
-    const int* it_nb;
-    const int* job_item0;  // [n_jobs+1]
-    const int* job_pair0;  // [n_items+1] prefix of pair counts (global)
-    const int* job_tile;   // [n_jobs] tile id
-    const int* job_ti;     // [n_jobs] tile row (for diagonal tiles also the g block)
-    const int* job_tj;     // [n_jobs]
-    double* slab;          // [n_jobs][TS*TS]
-    double* gslab;         // [n_jobs][TS]
-    // assembly lists per stored tile
-    const int* tile_job_ptr;  // [n_tiles+1]
-    const int* tile_jobs;     // job ids in fixed order
-    const int* tile_ti;       // [n_tiles]
-    const int* tile_tj;
-    const int* tile_aux_ptr;  // [n_tiles+1]
-    const int* tile_aux_ref;  // (se3 edge << 1) | transposed
+    // Schur reduction on 48 x 48 sub-tiles (8 x 8 poses): items, wavefront jobs, slabs
+    int n_items, n_jobs, n_sub;
+    const int* it_pack;      // [n_items][4]: landmark, first edge of the row segment, first edge of the column segment, maskI | maskJ << 8
+    const int* job_item0;    // [n_jobs+1]
+    const int* job_diag;     // [n_jobs] 1: diagonal sub-tile (lower blocks only, carries g)
+    double* slab;            // [n_jobs][36][64]  element q of the 6x6 block of lane (i = lane>>3, j = lane&7)
+    double* gslab;           // [n_jobs][6][8]
+    // assembly per stored sub-tile
+    const int* sub_job_ptr;  // [n_sub+1] (jobs of a sub-tile are consecutive)
+    const int* sub_cx;       // [n_sub] sub-tile row / column in units of 48
+    const int* sub_cy;
+    const int* sub_tile;     // [n_sub] tile id that holds it
+    const int* sub_aux_ptr;  // [n_sub+1]
+    const int* sub_aux_ref;  // (se3 edge << 1) | transposed
     int add_pose_terms;       // rank 0 adds Hpp / bp / odometry blocks
 
     // LM scalars on the device

@@ -387,28 +387,13 @@ int build_structure(svi_ba* ba)
     }
     row_ptr[NT] = (int)row_tile.size();
 
-    // ---- Schur items (local landmarks) grouped by tile into jobs ----
-    struct Item { int tile, lm, a0, na, b0, nb; };
-    std::vector<Item> items;
-    for (int l = 0; l < Ll; ++l) {
-        if (lm_fixed[l]) continue;
-        int a = lm_ptr[l];
-        const int end = lm_ptr[l + 1];
-        while (a < end && pose_red[e_pose[a]] < 0) ++a; // edges to fixed poses come first
-        std::vector<std::pair<int, int>> seg; // (begin, count), one per pose chunk
-        std::vector<int> seg_chunk;
-        while (a < end) {
-            const int c = pose_red[e_pose[a]] / PB;
-            int b = a;
-            while (b < end && pose_red[e_pose[b]] / PB == c) ++b;
-            seg.push_back({a, b - a});
-            seg_chunk.push_back(c);
-            a = b;
-        }
-        for (size_t x = 0; x < seg.size(); ++x)
-            for (size_t y = 0; y <= x; ++y)
-                items.push_back({tile_map[(size_t)seg_chunk[x] * NT + seg_chunk[y]], l, seg[x].first, seg[x].second, seg[y].first, seg[y].second});
-    }
+    // ---- Schur decomposition: always on 48 x 48 sub-tiles (8 poses x 8 poses), whatever TS is ----
+    // item  = (landmark, row chunk cX, column chunk cY): the poses of the landmark in either chunk as
+    //         8-bit masks plus the first lm-major edge of each segment
+    // job   = a run of items of ONE sub-tile, processed by one wavefront (lane = 6x6 block of the sub-tile)
+    constexpr int PBS = 8, SUB = 48;
+    const int Q = TS / SUB;          // sub-tiles per tile edge
+    const int NSUB = NT * Q;         // sub-tile rows of the padded system
     // duplicate (pose, landmark) edges would alias one 6x6 block inside an item; the reference never
     // creates them (one measurement per landmark per keyframe), reject instead of mis-summing
     for (int l = 0; l < Ll; ++l)
@@ -416,52 +401,77 @@ int build_structure(svi_ba* ba)
             if (e_pose[a] == e_pose[a - 1])
                 return fail(SVI_ERR_UNSUPPORTED, "two projection edges between pose %lld and landmark %lld",
                             (long long)ba->poses[ba->pose_order[e_pose[a]]].id, (long long)ba->lms[ba->lm_order[L0 + l]].id);
-    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.tile < b.tile; });
-    const int n_items = (int)items.size();
-    std::vector<int> it_lm(n_items), it_a0(n_items), it_na(n_items), it_b0(n_items), it_nb(n_items), job_pair0(n_items + 1, 0);
+    // stored sub-tiles: every lower sub-tile inside a stored tile (they all have to be (re)written per trial)
+    std::vector<int> sub_map((size_t)NSUB * NSUB, -1), sub_cx, sub_cy, sub_tile;
+    for (int t = 0; t < n_tiles; ++t)
+        for (int sx = 0; sx < Q; ++sx)
+            for (int sy = 0; sy < Q; ++sy) {
+                const int cx = tile_ti[t] * Q + sx, cy = tile_tj[t] * Q + sy;
+                if (cy > cx) continue;
+                sub_map[(size_t)cx * NSUB + cy] = (int)sub_cx.size();
+                sub_cx.push_back(cx); sub_cy.push_back(cy); sub_tile.push_back(t);
+            }
+    const int n_sub = (int)sub_cx.size();
+    struct Item { int sub, lm, a0, b0, masks; };
+    std::vector<Item> items;
     int64_t total_pairs = 0;
-    for (int i = 0; i < n_items; ++i) {
-        const Item& it = items[i];
-        it_lm[i] = it.lm; it_a0[i] = it.a0; it_na[i] = it.na; it_b0[i] = it.b0; it_nb[i] = it.nb;
-        const bool dg = tile_ti[it.tile] == tile_tj[it.tile];
-        const int64_t np = dg ? (int64_t)it.na * (it.na + 1) / 2 : (int64_t)it.na * it.nb;
-        total_pairs += np;
-        if (total_pairs > 0x7fffffff) return fail(SVI_ERR_UNSUPPORTED, "too many Schur block pairs for 32-bit indexing");
-        job_pair0[i + 1] = (int)total_pairs;
+    for (int l = 0; l < Ll; ++l) {
+        if (lm_fixed[l]) continue;
+        int a = lm_ptr[l];
+        const int end = lm_ptr[l + 1];
+        while (a < end && pose_red[e_pose[a]] < 0) ++a; // edges to fixed poses come first
+        struct Seg { int chunk, begin, mask, count; };
+        std::vector<Seg> seg;
+        while (a < end) {
+            const int c = pose_red[e_pose[a]] / PBS;
+            Seg sg{c, a, 0, 0};
+            while (a < end && pose_red[e_pose[a]] / PBS == c) { sg.mask |= 1 << (pose_red[e_pose[a]] % PBS); ++sg.count; ++a; }
+            seg.push_back(sg);
+        }
+        for (size_t x = 0; x < seg.size(); ++x)
+            for (size_t y = 0; y <= x; ++y) {
+                const int sub = sub_map[(size_t)seg[x].chunk * NSUB + seg[y].chunk];
+                if (sub < 0) return fail(SVI_ERR_STATE, "internal: Schur sub-tile outside the tile structure");
+                items.push_back({sub, l, seg[x].begin, seg[y].begin, seg[x].mask | (seg[y].mask << 8)});
+                total_pairs += (x == y) ? (int64_t)seg[x].count * (seg[x].count + 1) / 2 : (int64_t)seg[x].count * seg[y].count;
+            }
     }
-    const int64_t target = std::max<int64_t>(2048, total_pairs / 1024);
-    std::vector<int> job_item0(1, 0), job_tile, job_ti, job_tj;
+    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.sub < b.sub; });
+    const int n_items = (int)items.size();
+    std::vector<int> it_pack((size_t)4 * std::max(n_items, 1));
+    for (int i = 0; i < n_items; ++i) {
+        it_pack[4 * i] = items[i].lm; it_pack[4 * i + 1] = items[i].a0; it_pack[4 * i + 2] = items[i].b0; it_pack[4 * i + 3] = items[i].masks;
+    }
+    const int target = (int)std::min<int64_t>(1024, std::max<int64_t>(48, n_items / 1536));
+    std::vector<int> job_item0(1, 0), job_sub;
     for (int i = 0; i < n_items;) {
-        const int tile = items[i].tile;
+        const int sub = items[i].sub;
         int j = i;
-        const int64_t base = job_pair0[i];
-        while (j < n_items && items[j].tile == tile && (j == i || job_pair0[j + 1] - base <= target)) ++j;
-        job_tile.push_back(tile); job_ti.push_back(tile_ti[tile]); job_tj.push_back(tile_tj[tile]);
+        while (j < n_items && items[j].sub == sub && j - i < target) ++j;
+        job_sub.push_back(sub);
         job_item0.push_back(j);
         i = j;
     }
-    const int n_jobs = (int)job_tile.size();
-    std::vector<int> tile_job_ptr(n_tiles + 1, 0), tile_jobs(n_jobs);
-    for (int j = 0; j < n_jobs; ++j) tile_job_ptr[job_tile[j] + 1]++;
-    for (int t = 0; t < n_tiles; ++t) tile_job_ptr[t + 1] += tile_job_ptr[t];
-    {
-        std::vector<int> fill(tile_job_ptr.begin(), tile_job_ptr.end() - 1);
-        for (int j = 0; j < n_jobs; ++j) tile_jobs[fill[job_tile[j]]++] = j;
-    }
-    std::vector<std::vector<int>> taux(n_tiles);
+    const int n_jobs = (int)job_sub.size();
+    std::vector<int> sub_job_ptr(n_sub + 1, 0), job_diag(std::max(n_jobs, 1), 0);
+    for (int j = 0; j < n_jobs; ++j) { sub_job_ptr[job_sub[j] + 1]++; job_diag[j] = sub_cx[job_sub[j]] == sub_cy[job_sub[j]]; }
+    for (int t = 0; t < n_sub; ++t) sub_job_ptr[t + 1] += sub_job_ptr[t]; // jobs of a sub-tile are consecutive
+    std::vector<std::vector<int>> taux(n_sub);
     for (int k = 0; k < (int)se3_i.size(); ++k) {
         const int ri = pose_red[se3_i[k]], rj = pose_red[se3_j[k]];
         if (ri < 0 || rj < 0 || ri == rj) continue;
         const int tr = ri > rj ? 0 : 1; // row pose = the one with the larger reduced index
         const int hi = std::max(ri, rj), lo = std::min(ri, rj);
-        taux[tile_map[(size_t)(hi / PB) * NT + lo / PB]].push_back((k << 1) | tr);
+        const int sub = sub_map[(size_t)(hi / PBS) * NSUB + lo / PBS];
+        if (sub < 0) return fail(SVI_ERR_STATE, "internal: odometry block outside the tile structure");
+        taux[sub].push_back((k << 1) | tr);
     }
-    std::vector<int> tile_aux_ptr(n_tiles + 1, 0), tile_aux_ref;
-    for (int t = 0; t < n_tiles; ++t) {
-        tile_aux_ptr[t] = (int)tile_aux_ref.size();
-        tile_aux_ref.insert(tile_aux_ref.end(), taux[t].begin(), taux[t].end());
+    std::vector<int> sub_aux_ptr(n_sub + 1, 0), sub_aux_ref;
+    for (int t = 0; t < n_sub; ++t) {
+        sub_aux_ptr[t] = (int)sub_aux_ref.size();
+        sub_aux_ref.insert(sub_aux_ref.end(), taux[t].begin(), taux[t].end());
     }
-    tile_aux_ptr[n_tiles] = (int)tile_aux_ref.size();
+    sub_aux_ptr[n_sub] = (int)sub_aux_ref.size();
 
     // ---- upload ----
     d.Pn = Pn; d.Pf = Pf; d.Ll = Ll; d.E = E;
@@ -533,25 +543,18 @@ int build_structure(svi_ba* ba)
     SVI_TRY(dev_alloc(ba, (size_t)NT * TS * TS, &d.Linv));
     SVI_TRY(dev_alloc(ba, (size_t)NT * TS, &d.dx));
     SVI_TRY(dev_alloc(ba, 1, &d.chol_status));
-    d.n_items = n_items; d.n_jobs = n_jobs;
-    SVI_TRY(dev_upload(ba, it_lm, &d.it_lm));
-    SVI_TRY(dev_upload(ba, it_a0, &d.it_a0));
-    SVI_TRY(dev_upload(ba, it_na, &d.it_na));
-    SVI_TRY(dev_upload(ba, it_b0, &d.it_b0));
-    SVI_TRY(dev_upload(ba, it_nb, &d.it_nb));
+    d.n_items = n_items; d.n_jobs = n_jobs; d.n_sub = n_sub;
+    SVI_TRY(dev_upload(ba, it_pack, &d.it_pack));
     SVI_TRY(dev_upload(ba, job_item0, &d.job_item0));
-    SVI_TRY(dev_upload(ba, job_pair0, &d.job_pair0));
-    SVI_TRY(dev_upload(ba, job_tile, &d.job_tile));
-    SVI_TRY(dev_upload(ba, job_ti, &d.job_ti));
-    SVI_TRY(dev_upload(ba, job_tj, &d.job_tj));
-    SVI_TRY(dev_alloc(ba, (size_t)n_jobs * TS * TS, &d.slab, false));
-    SVI_TRY(dev_alloc(ba, (size_t)n_jobs * TS, &d.gslab, false));
-    SVI_TRY(dev_upload(ba, tile_job_ptr, &d.tile_job_ptr));
-    SVI_TRY(dev_upload(ba, tile_jobs, &d.tile_jobs));
-    SVI_TRY(dev_upload(ba, tile_ti, &d.tile_ti));
-    SVI_TRY(dev_upload(ba, tile_tj, &d.tile_tj));
-    SVI_TRY(dev_upload(ba, tile_aux_ptr, &d.tile_aux_ptr));
-    SVI_TRY(dev_upload(ba, tile_aux_ref, &d.tile_aux_ref));
+    SVI_TRY(dev_upload(ba, job_diag, &d.job_diag));
+    SVI_TRY(dev_alloc(ba, (size_t)std::max(n_jobs, 1) * 36 * 64, &d.slab, false));
+    SVI_TRY(dev_alloc(ba, (size_t)std::max(n_jobs, 1) * 6 * 8, &d.gslab, false));
+    SVI_TRY(dev_upload(ba, sub_job_ptr, &d.sub_job_ptr));
+    SVI_TRY(dev_upload(ba, sub_cx, &d.sub_cx));
+    SVI_TRY(dev_upload(ba, sub_cy, &d.sub_cy));
+    SVI_TRY(dev_upload(ba, sub_tile, &d.sub_tile));
+    SVI_TRY(dev_upload(ba, sub_aux_ptr, &d.sub_aux_ptr));
+    SVI_TRY(dev_upload(ba, sub_aux_ref, &d.sub_aux_ref));
     d.add_pose_terms = (o.rank == 0) ? 1 : 0;
     SVI_TRY(dev_alloc(ba, 16, &d.scal));
     if (o.n_ranks > 1) SVI_TRY(dev_alloc(ba, (size_t)3 * Ltot, &ba->lm_all));

@@ -447,128 +447,190 @@ __global__ __launch_bounds__(kBlock) void k_invert_landmarks(BaDev d, double lam
 }
 
 // ---------------------------------------------------------------------------------------------
-// K4: Schur reduction, S-tile major.  One workgroup per job = a batch of (landmark, row segment,
-// column segment) items that all fall into one TS x TS tile of S.  Each lane takes one pose pair
-// (a,b) of one landmark:  block = (W_a Hinv_l) W_b'  (6x6), accumulated in an LDS image of the tile
-// with ds_add_f64, then the tile image is stored to this job's slab.
+// K4: Schur reduction on 48 x 48 sub-tiles of S.  One WAVEFRONT per job (a run of items of one
+// sub-tile); lane (i,j) = (lane>>3, lane&7) owns the 6x6 block of pose pair (8 cX + i, 8 cY + j) and
+// accumulates it in registers: for every item (landmark) whose masks contain both poses,
+//     block += (W_a Hinv_l) W_b'        (a, b = the landmark's edges to those two poses)
+// No atomics, fixed summation order.  Diagonal sub-tiles keep the lower blocks only and carry the
+// right-hand side  g_i += (W_a Hinv_l) b_l.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
-{
-    extern __shared__ __align__(16) double s_tile[]; // [TS*TS] + [TS]
-    const int TS = d.TS, PB = TS / 6;
-    double* s_g = s_tile + TS * TS;
-    const int job = blockIdx.x, tid = threadIdx.x;
-    for (int i = tid; i < TS * TS + TS; i += kBlock) s_tile[i] = 0.0;
-    __syncthreads();
+constexpr int kSchurBatch = 4;             // items staged per wave and pass
+constexpr int kSchurSlot  = 16 * 18 + 12;  // doubles per staged item: 16 edge slots x H_pl(18), Hinv(6), b_l(3), pad
 
-    const int it0 = d.job_item0[job], it1 = d.job_item0[job + 1];
-    const int p0 = d.job_pair0[it0], p1 = d.job_pair0[it1];
-    const bool diag = d.job_ti[job] == d.job_tj[job];
+struct SchurStage { double v[kSchurBatch][5]; double hv[kSchurBatch]; };
+
+// issue the global loads of the items [base, base+nb) of a job (staging role: edge slot es, planes pg, pg+4, ...)
+__device__ __forceinline__ void schur_fetch(const BaDev& d, const int4* __restrict__ items, int base, int nb, bool diag, int lane,
+                                            SchurStage& st)
+{
+    const int es = lane & 15, pg = lane >> 4;
     const size_t E = d.E, Ll = d.Ll;
-    for (int p = p0 + tid; p < p1; p += kBlock) {
-        // item containing pair p
-        int lo = it0, hi = it1 - 1;
-        while (lo < hi) {
-            const int mid = (lo + hi + 1) >> 1;
-            if (d.job_pair0[mid] <= p) lo = mid; else hi = mid - 1;
-        }
-        const int it = lo, q = p - d.job_pair0[it];
-        int al, bl_;
-        if (diag) { // lower triangle incl. diagonal: q = al(al+1)/2 + bl
-            al = (int)((sqrt(8.0 * q + 1.0) - 1.0) * 0.5);
-            while ((al + 1) * (al + 2) / 2 <= q) ++al;
-            while (al * (al + 1) / 2 > q) --al;
-            bl_ = q - al * (al + 1) / 2;
-        } else {
-            const int nb = d.it_nb[it];
-            al = q / nb; bl_ = q - al * nb;
-        }
-        const int ea = d.it_a0[it] + al, eb = d.it_b0[it] + bl_;
-        const int l = d.it_lm[it];
-        const int ra = d.pose_red[d.e_pose[ea]], rb = d.pose_red[d.e_pose[eb]];
-        const int li = (ra % PB) * 6, lj = (rb % PB) * 6;
-        double Hi[6];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) Hi[k] = d.Hinv[(size_t)k * Ll + l];
-        double T[18]; // W_a Hinv
+    for (int t = 0; t < kSchurBatch; ++t) {
+        if (t < nb) {
+            const int4 pk = items[base + t];
+            const unsigned mI = (unsigned)pk.w & 0xFFu, mJ = ((unsigned)pk.w >> 8) & 0xFFu;
+            const int nI = __popc(mI), nJ = diag ? 0 : __popc(mJ);
+            long long e = -1;
+            if (es < 8) { if (es < nI) e = (long long)pk.y + es; }
+            else if (es - 8 < nJ) e = (long long)pk.z + (es - 8);
 #pragma unroll
-        for (int i = 0; i < 6; ++i) {
-            const double w0 = d.W[(size_t)(3 * i) * E + ea], w1 = d.W[(size_t)(3 * i + 1) * E + ea], w2 = d.W[(size_t)(3 * i + 2) * E + ea];
-            T[3 * i]     = w0 * Hi[0] + w1 * Hi[1] + w2 * Hi[2];
-            T[3 * i + 1] = w0 * Hi[1] + w1 * Hi[3] + w2 * Hi[4];
-            T[3 * i + 2] = w0 * Hi[2] + w1 * Hi[4] + w2 * Hi[5];
-        }
-#pragma unroll
-        for (int j = 0; j < 6; ++j) {
-            const double w0 = d.W[(size_t)(3 * j) * E + eb], w1 = d.W[(size_t)(3 * j + 1) * E + eb], w2 = d.W[(size_t)(3 * j + 2) * E + eb];
-#pragma unroll
-            for (int i = 0; i < 6; ++i)
-                atomicAdd(&s_tile[(li + i) * TS + lj + j], T[3 * i] * w0 + T[3 * i + 1] * w1 + T[3 * i + 2] * w2);
-        }
-        if (diag && al == bl_) {
-            const double b0 = d.bl[l], b1 = d.bl[Ll + l], b2 = d.bl[2 * Ll + l];
-#pragma unroll
-            for (int i = 0; i < 6; ++i) atomicAdd(&s_g[li + i], T[3 * i] * b0 + T[3 * i + 1] * b1 + T[3 * i + 2] * b2);
+            for (int q = 0; q < 5; ++q) {
+                const int p = pg + 4 * q;
+                st.v[t][q] = (e >= 0 && p < 18) ? d.W[(size_t)p * E + (size_t)e] : 0.0;
+            }
+            st.hv[t] = (lane < 6) ? d.Hinv[(size_t)lane * Ll + pk.x] : ((lane < 9) ? d.bl[(size_t)(lane - 6) * Ll + pk.x] : 0.0);
         }
     }
-    __syncthreads();
-    double* out = d.slab + (size_t)job * TS * TS;
-    for (int i = tid; i < TS * TS; i += kBlock) out[i] = s_tile[i];
-    if (diag) for (int i = tid; i < TS; i += kBlock) d.gslab[(size_t)job * TS + i] = s_g[i];
+}
+
+__device__ __forceinline__ void schur_stash(const SchurStage& st, int nb, int lane, double (*slots)[kSchurSlot])
+{
+    const int es = lane & 15, pg = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < kSchurBatch; ++t) {
+        if (t < nb) {
+#pragma unroll
+            for (int q = 0; q < 5; ++q) {
+                const int p = pg + 4 * q;
+                if (p < 18) slots[t][es * 18 + p] = st.v[t][q];
+            }
+            if (lane < 9) slots[t][288 + lane] = st.hv[t];
+        }
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
+{
+    // The operands of kSchurBatch items are staged in a wave-private LDS region, double buffered: the
+    // global loads of batch k+1 are in flight while batch k is being multiplied out of LDS.
+    __shared__ double s_stage[kBlock / 64][2][kSchurBatch][kSchurSlot];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int job = blockIdx.x * (kBlock / 64) + wave; // wave-uniform: item records come through the scalar cache
+    if (job >= d.n_jobs) return;
+    const int i = lane >> 3, j = lane & 7;
+    const int it0 = d.job_item0[job], it1 = d.job_item0[job + 1];
+    const bool diag = d.job_diag[job] != 0;
+    const int4* __restrict__ items = reinterpret_cast<const int4*>(d.it_pack);
+    double acc[36], gacc[6];
+#pragma unroll
+    for (int q = 0; q < 36; ++q) acc[q] = 0.0;
+#pragma unroll
+    for (int q = 0; q < 6; ++q) gacc[q] = 0.0;
+    const unsigned below_i = (1u << i) - 1u, below_j = (1u << j) - 1u;
+    SchurStage st;
+    int buf = 0;
+    schur_fetch(d, items, it0, min(kSchurBatch, it1 - it0), diag, lane, st);
+    for (int base = it0; base < it1; base += kSchurBatch, buf ^= 1) {
+        const int nb = min(kSchurBatch, it1 - base);
+        schur_stash(st, nb, lane, s_stage[wave][buf]);
+        const int nbase = base + kSchurBatch;
+        if (nbase < it1) schur_fetch(d, items, nbase, min(kSchurBatch, it1 - nbase), diag, lane, st);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        int4 pks[kSchurBatch];
+#pragma unroll
+        for (int t = 0; t < kSchurBatch; ++t) pks[t] = items[base + (t < nb ? t : 0)];
+#pragma unroll
+        for (int t = 0; t < kSchurBatch; ++t) {
+            if (t >= nb) break;
+            const int4 pk = pks[t];
+            const unsigned mI = (unsigned)pk.w & 0xFFu, mJ = ((unsigned)pk.w >> 8) & 0xFFu;
+            const bool active = ((mI >> i) & 1u) && ((mJ >> j) & 1u) && (!diag || i >= j);
+            if (!active) continue;
+            const double* slot = s_stage[wave][buf][t];
+            const double* wa = slot + 18 * __popc(mI & below_i);
+            const double* wb = slot + 18 * (diag ? __popc(mJ & below_j) : 8 + __popc(mJ & below_j));
+            const double* Hi = slot + 288;
+            double T[18]; // W_a Hinv
+#pragma unroll
+            for (int r = 0; r < 6; ++r) {
+                const double w0 = wa[3 * r], w1 = wa[3 * r + 1], w2 = wa[3 * r + 2];
+                T[3 * r]     = w0 * Hi[0] + w1 * Hi[1] + w2 * Hi[2];
+                T[3 * r + 1] = w0 * Hi[1] + w1 * Hi[3] + w2 * Hi[4];
+                T[3 * r + 2] = w0 * Hi[2] + w1 * Hi[4] + w2 * Hi[5];
+            }
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const double w0 = wb[3 * c], w1 = wb[3 * c + 1], w2 = wb[3 * c + 2];
+#pragma unroll
+                for (int r = 0; r < 6; ++r) acc[6 * r + c] += T[3 * r] * w0 + T[3 * r + 1] * w1 + T[3 * r + 2] * w2;
+            }
+            if (diag && i == j) {
+#pragma unroll
+                for (int r = 0; r < 6; ++r) gacc[r] += T[3 * r] * Hi[6] + T[3 * r + 1] * Hi[7] + T[3 * r + 2] * Hi[8];
+            }
+        }
+        // the buffer written two iterations from now is this one: every lane is past its reads by then
+        // (wave-synchronous execution, in-order LDS), the barrier below keeps the compiler honest
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+    }
+    double* out = d.slab + (size_t)job * 36 * 64;
+#pragma unroll
+    for (int q = 0; q < 36; ++q) out[q * 64 + lane] = acc[q];
+    if (diag && i == j) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) d.gslab[((size_t)job * 6 + q) * 8 + i] = gacc[q];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
-// K4b: one workgroup per stored tile of S: pose terms (H_pp diagonal blocks, odometry blocks) minus
-// the job slabs of this tile, summed in a fixed order.  Diagonal tiles also assemble their part of g.
+// K4b: one workgroup per stored 48 x 48 sub-tile of S: pose terms (H_pp diagonal blocks, odometry
+// blocks) minus the job slabs of this sub-tile, summed in a fixed order, written into its tile.
+// Diagonal sub-tiles also assemble their part of g and the identity padding of the last rows.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_assemble(BaDev d)
 {
-    extern __shared__ __align__(16) double s_tile[]; // [TS*TS]
-    const int TS = d.TS, PB = TS / 6, n = 6 * d.Pf;
-    const int tile = blockIdx.x, tid = threadIdx.x;
-    const int ti = d.tile_ti[tile], tj = d.tile_tj[tile];
-    for (int i = tid; i < TS * TS; i += kBlock) s_tile[i] = 0.0;
+    __shared__ double s_t[48][49];
+    const int sub = blockIdx.x, tid = threadIdx.x;
+    const int cx = d.sub_cx[sub], cy = d.sub_cy[sub], n = 6 * d.Pf, TS = d.TS;
+    const int j0 = d.sub_job_ptr[sub], j1 = d.sub_job_ptr[sub + 1];
+    // slabs: element e = q*64 + lane  ->  block (i,j) = (lane>>3, lane&7), entry (rr,cc) = (q/6, q%6)
+    for (int e = tid; e < 36 * 64; e += kBlock) {
+        double v = 0.0;
+        for (int jb = j0; jb < j1; ++jb) v -= d.slab[(size_t)jb * 36 * 64 + e];
+        const int q = e >> 6, lane = e & 63;
+        s_t[(lane >> 3) * 6 + q / 6][(lane & 7) * 6 + q % 6] = v;
+    }
     __syncthreads();
     if (d.add_pose_terms) {
-        if (ti == tj) {
-            for (int i = tid; i < PB * 36; i += kBlock) {
-                const int pl = i / 36, rr = (i % 36) / 6, cc = i % 6;
-                const int r = ti * PB + pl;
+        if (cx == cy) {
+            for (int e = tid; e < 8 * 36; e += kBlock) {
+                const int pl = e / 36, rr = (e % 36) / 6, cc = e % 6;
+                const int r = cx * 8 + pl;
                 if (r < d.Pf) {
                     const int a = rr < cc ? rr : cc, b = rr < cc ? cc : rr;
-                    s_tile[(pl * 6 + rr) * TS + pl * 6 + cc] = d.Hpp[(size_t)21 * r + (a * 6 - a * (a - 1) / 2) + (b - a)];
+                    s_t[pl * 6 + rr][pl * 6 + cc] += d.Hpp[(size_t)21 * r + (a * 6 - a * (a - 1) / 2) + (b - a)];
                 }
             }
         }
         __syncthreads();
-        for (int q = d.tile_aux_ptr[tile] * 36 + tid; q < d.tile_aux_ptr[tile + 1] * 36; q += kBlock) {
-            const int ref = d.tile_aux_ref[q / 36], k = ref >> 1, tr = ref & 1;
-            const int rr = (q % 36) / 6, cc = q % 6;
+        for (int e = d.sub_aux_ptr[sub] * 36 + tid; e < d.sub_aux_ptr[sub + 1] * 36; e += kBlock) {
+            const int ref = d.sub_aux_ref[e / 36], k = ref >> 1, tr = ref & 1;
+            const int rr = (e % 36) / 6, cc = e % 6;
             const int ri = d.pose_red[d.se3_i[k]], rj = d.pose_red[d.se3_j[k]];
             const int rhi = tr ? rj : ri, rlo = tr ? ri : rj; // row pose, column pose of the lower block
             const double v = tr ? d.se3_out[(size_t)120 * k + 72 + 6 * cc + rr] : d.se3_out[(size_t)120 * k + 72 + 6 * rr + cc];
-            atomicAdd(&s_tile[((rhi % PB) * 6 + rr) * TS + (rlo % PB) * 6 + cc], v);
+            atomicAdd(&s_t[(rhi % 8) * 6 + rr][(rlo % 8) * 6 + cc], v);
         }
+        __syncthreads();
     }
-    __syncthreads();
-    const int j0 = d.tile_job_ptr[tile], j1 = d.tile_job_ptr[tile + 1];
-    double* out = d.S + (size_t)tile * TS * TS;
-    for (int i = tid; i < TS * TS; i += kBlock) {
-        double v = s_tile[i];
-        for (int j = j0; j < j1; ++j) v -= d.slab[(size_t)d.tile_jobs[j] * TS * TS + i];
-        if (ti == tj) { // padding rows of the last tile: identity
-            const int rr = i / TS, cc = i % TS;
-            if (ti * TS + rr >= n || ti * TS + cc >= n) v = (rr == cc) ? 1.0 : 0.0;
-        }
-        out[i] = v;
+    const int R0 = cx * 48, C0 = cy * 48;
+    double* out = d.S + (size_t)d.sub_tile[sub] * TS * TS + (size_t)(R0 % TS) * TS + (C0 % TS);
+    for (int e = tid; e < 48 * 48; e += kBlock) {
+        const int r = e / 48, c = e % 48;
+        double v = s_t[r][c];
+        if (R0 + r >= n || C0 + c >= n) v = (R0 + r == C0 + c) ? 1.0 : 0.0; // identity padding
+        out[(size_t)r * TS + c] = v;
     }
-    if (ti == tj) {
-        for (int i = tid; i < TS; i += kBlock) {
-            const int row = ti * TS + i;
+    if (cx == cy) {
+        for (int r = tid; r < 48; r += kBlock) {
+            const int row = R0 + r;
             double v = 0.0;
             if (row < n) {
                 if (d.add_pose_terms) v = d.bp[row];
-                for (int j = j0; j < j1; ++j) v -= d.gslab[(size_t)d.tile_jobs[j] * TS + i];
+                for (int jb = j0; jb < j1; ++jb) v -= d.gslab[((size_t)jb * 6 + r % 6) * 8 + r / 6];
             }
             d.g[row] = v;
         }
@@ -774,13 +836,11 @@ void ba_invert_landmarks(const BaDev& d, double lambda, void* st)
 }
 void ba_schur(const BaDev& d, void* st)
 {
-    const size_t lds = sizeof(double) * ((size_t)d.TS * d.TS + d.TS);
-    if (d.n_jobs > 0) hipLaunchKernelGGL(k_schur, dim3(d.n_jobs), dim3(kBlock), lds, S_(st), d);
+    if (d.n_jobs > 0) hipLaunchKernelGGL(k_schur, dim3((d.n_jobs + 3) / 4), dim3(kBlock), 0, S_(st), d);
 }
 void ba_assemble(const BaDev& d, void* st)
 {
-    const size_t lds = sizeof(double) * (size_t)d.TS * d.TS;
-    if (d.n_tiles > 0) hipLaunchKernelGGL(k_assemble, dim3(d.n_tiles), dim3(kBlock), lds, S_(st), d);
+    if (d.n_sub > 0) hipLaunchKernelGGL(k_assemble, dim3(d.n_sub), dim3(kBlock), 0, S_(st), d);
 }
 void ba_update_poses(const BaDev& d, int cur, double lambda, void* st)
 {
@@ -803,12 +863,6 @@ void ba_debug_jacobians(const BaDev& d, int cur, const int* e_orig, double* err,
     if (d.E > 0) hipLaunchKernelGGL(k_debug_jacobians, dim3((d.E + kBlock - 1) / kBlock), dim3(kBlock), 0, S_(st), d, cur, e_orig, err, Jp, Jl);
 }
 
-// dynamic LDS above 64 KB has to be requested per kernel
-void ba_configure_kernels(int TS)
-{
-    const int lds = (int)(sizeof(double) * ((size_t)TS * TS + TS));
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_schur), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k_assemble), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-}
+void ba_configure_kernels(int) {}
 
 } // namespace svi
