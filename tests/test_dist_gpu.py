@@ -1,0 +1,125 @@
+"""The landmark-sharded BA on real kernels: two shards of one graph, their reduced systems summed
+through the all-reduce hook, must reproduce the unsharded solve."""
+import threading
+
+import numpy as np
+import pytest
+
+from svi_mapper_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+def _run_sharded(svi, prob, n_ranks, iters):
+    """n_ranks handles in n_ranks threads of one process; the hook sums their buffers in a fixed order."""
+    import torch
+    cam = prob["cam"]
+    barrier = threading.Barrier(n_ranks)
+    slots = [None] * n_ranks
+    out = [None] * n_ranks
+    errs = []
+
+    def hook_for(rank):
+        def hook(ptr, count, stream):
+            from svi_mapper_amd.dist import _DevPtr
+            ext = torch.cuda.ExternalStream(stream)
+            t = torch.as_tensor(_DevPtr(ptr, count), device="cuda:0")
+            ext.synchronize()
+            slots[rank] = t
+            barrier.wait()
+            if rank == 0:
+                total = slots[0].clone()
+                for r in range(1, n_ranks):
+                    total += slots[r]
+                for r in range(n_ranks):
+                    slots[r].copy_(total)
+                torch.cuda.synchronize()
+            barrier.wait()
+            return 0
+        return hook
+
+    def work(rank):
+        try:
+            ba = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"], rank=rank, n_ranks=n_ranks)
+            synth.build_ba_graph(ba, prob)
+            ba.set_allreduce(hook_for(rank))
+            ba.initialize()
+            done = [ba.optimize(n) for n in iters]
+            out[rank] = (done, ba.get_poses()[1], ba.get_landmarks()[1], ba.chi2(), ba.stats().n_landmarks_local)
+            ba.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+            barrier.abort()
+
+    th = [threading.Thread(target=work, args=(r,)) for r in range(n_ranks)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(300)
+    if errs:
+        raise errs[0]
+    return out
+
+
+@pytest.mark.parametrize("n_ranks", [2, 3])
+def test_sharded_equals_unsharded(svi, n_ranks):
+    prob = synth.make_ba_problem(30, 2000, 15000, seed=21)
+    cam = prob["cam"]
+    iters = (1, 5)
+    ref = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"])
+    synth.build_ba_graph(ref, prob)
+    ref.initialize()
+    done = [ref.optimize(n) for n in iters]
+    _, T, = ref.get_poses()
+    _, p = ref.get_landmarks()
+    out = _run_sharded(svi, prob, n_ranks, iters)
+    locals_ = [o[4] for o in out]
+    assert sum(locals_) == prob["n_lm"] and min(locals_) > 0
+    for o in out:
+        assert o[0] == done
+        assert np.abs(o[1] - T).max() < 1e-9
+        assert np.abs(o[2] - p).max() < 1e-9 * max(1.0, np.abs(p).max())  # every rank ends up with ALL landmarks
+        assert abs(o[3][0] - ref.chi2()[0]) <= 1e-9 * ref.chi2()[0]
+
+
+def test_missing_hook_fails_loudly(svi):
+    prob = synth.make_ba_problem(6, 60, 330, seed=42)
+    cam = prob["cam"]
+    ba = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"], rank=0, n_ranks=2)
+    synth.build_ba_graph(ba, prob)
+    ba.initialize()
+    with pytest.raises(svi.SviError) as e:
+        ba.optimize(1)
+    assert e.value.status == 4
+
+
+def test_rccl_hook_aliases_library_memory(svi):
+    """svi_mapper_amd.dist.make_allreduce_hook on a 1-rank RCCL group: the hook must wrap the raw device
+    pointer without copying and run the collective on the given stream (sum over 1 rank = identity)."""
+    import os
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from svi_mapper_amd import dist as sdist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        hook = sdist.make_allreduce_hook()
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            x = torch.arange(1000, dtype=torch.float64, device="cuda")
+        assert hook(x.data_ptr(), x.numel(), st.cuda_stream) == 0
+        with torch.cuda.stream(st):
+            x += 1.0  # ordered after the collective on the same stream
+        st.synchronize()
+        assert torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float64) + 1.0)
+    finally:
+        dist.destroy_process_group()
