@@ -256,8 +256,8 @@ int svi_ba_set_allreduce(svi_ba* ba, svi_allreduce_fn fn, void* user);
 
 /* --- instrumentation ----------------------------------------------------------------------- */
 enum svi_ba_phase {
-    SVI_PH_LINEARIZE_LM   = 0, /* K2: landmark-major Jacobian sweep -> H_ll, b_l, H_pl        */
-    SVI_PH_LINEARIZE_POSE = 1, /* K3: pose-major Jacobian sweep -> H_pp, b_p                  */
+    SVI_PH_LINEARIZE_LM   = 0, /* K2+K3: the Jacobian sweep -> H_pl, H_ll, b_l, per-pose H_pp/b_p records */
+    SVI_PH_LINEARIZE_POSE = 1, /* (unused since the pose sums were folded into the sweep)     */
     SVI_PH_POSE_EDGES     = 2, /* odometry / gravity / landmark-closure edges                 */
     SVI_PH_SCHUR          = 3, /* K4: per-landmark inverse + windowed S, g contributions      */
     SVI_PH_ASSEMBLE       = 4, /* K4b: ordered reduction of the windows into the tile store  */
@@ -292,6 +292,10 @@ int svi_ba_debug_edge_jacobians(svi_ba* ba, double* err /*E x 3*/, double* J_pos
  * S (n x n row-major, full symmetric) and g (n), n = 6 * free poses; *n_out receives n */
 int svi_ba_debug_reduced_system(svi_ba* ba, double lambda, double* S, double* g, int64_t cap,
                                 int64_t* n_out);
+
+/* mean duration (ms) of the Jacobian sweep kernel over `reps` back-to-back launches on the handle's stream,
+ * bracketed by two HIP events (the state is not modified: the sweep only writes linearisation outputs) */
+int svi_ba_debug_time_sweep(svi_ba* ba, int reps, double* ms_avg);
 
 /* timing probe of the diagonal-tile Cholesky kernel (tile 48 or 96): mean ms per launch over `reps`
  * launches, truncated after phase `stop_after` (0 full, 1 pivot sweep, 2 +scale/store, 3 +diagonal

@@ -60,6 +60,7 @@ SVI_HD void proj_eval(int type, const double* R, const double* t, const double* 
     J0[24] = R[2]; J0[25] = R[5]; J0[26] = R[8];
     if (type == 0) {
         e[0] = Z[0] - z[0]; e[1] = Z[1] - z[1]; e[2] = Z[2] - z[2];
+#pragma unroll
         for (int k = 0; k < 27; ++k) J[k] = J0[k];
         return;
     }
@@ -68,6 +69,7 @@ SVI_HD void proj_eval(int type, const double* R, const double* t, const double* 
     e[1] = py / pz - z[1];
     e[2] = (type == 1 ? pz : 1.0 / pz) - z[2];
     const double iz2 = 1.0 / (pz * pz);
+#pragma unroll
     for (int c = 0; c < 9; ++c) {
         const double a0 = fx * J0[c] + cx * J0[18 + c];
         const double a1 = fy * J0[9 + c] + cy * J0[18 + c];

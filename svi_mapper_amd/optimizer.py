@@ -239,6 +239,12 @@ class BundleAdjuster:
     def reset_phase_times(self):
         check(self._lib.svi_ba_reset_phase_times(self._h), "svi_ba_reset_phase_times")
 
+    def time_sweep(self, reps=50):
+        """mean ms of the Jacobian sweep kernel (HIP events around `reps` back-to-back launches)"""
+        v = C.c_double(0)
+        check(self._lib.svi_ba_debug_time_sweep(self._h, int(reps), C.byref(v)), "svi_ba_debug_time_sweep")
+        return v.value
+
     def edge_jacobians(self):
         n = self.stats().n_edges_proj
         e = np.zeros((n, 3))
