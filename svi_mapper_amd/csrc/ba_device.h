@@ -79,7 +79,8 @@ struct BaDev {
     const int*    pose_aux_ref; // se3 edge k as (k<<2)|0 (role i) or |1 (role j); accel edge k as (k<<2)|2
 
     // linearisation outputs
-    double* W;        // [18][E]  H_pl per edge = J_p' (rho1 Omega) J_l, row-major 6x3 -> plane 3*a+c
+    double* NZ;       // [12][E]  per edge: N = A'(rho1 Omega)A R' (3x3 row-major, planes 0-8) and Z = R'(p-t) (planes 9-11);
+                      //          H_pl = [ -N ; -2[Z]x N ] is never materialised
     double* Hll;      // [6][Ll]  upper triangle of H_ll
     double* bl;       // [3][Ll]
     double* Hinv;     // [6][Ll]  (H_ll + lambda I)^-1, per trial

@@ -523,7 +523,7 @@ int build_structure(svi_ba* ba)
         SVI_TRY(dev_upload(ba, red_slot, &p)); ba->red_slot = const_cast<int*>(p);
         SVI_TRY(dev_upload(ba, e_orig, &p)); ba->e_orig = const_cast<int*>(p);
     }
-    SVI_TRY(dev_alloc(ba, (size_t)18 * E, &d.W));
+    SVI_TRY(dev_alloc(ba, (size_t)12 * E, &d.NZ));
     SVI_TRY(dev_alloc(ba, (size_t)6 * Ll, &d.Hll));
     SVI_TRY(dev_alloc(ba, (size_t)3 * Ll, &d.bl));
     SVI_TRY(dev_alloc(ba, (size_t)6 * Ll, &d.Hinv));
@@ -1175,6 +1175,28 @@ int svi_debug_chol_probe(int device, int tile, int reps, int stop_after, double*
     // stop_after == 6: shader cycles of the pivot sweep in ms[0] and 100 MHz ticks in ms[1] (caller passes room for 2)
     ms[0] = out[0];
     if (stop_after >= 6 && stop_after <= 9) ms[1] = out[1];
+    return SVI_OK;
+}
+
+// mean duration of the Jacobian sweep (K2 + K3): `reps` back-to-back sweeps on the handle's stream between two HIP events
+int svi_ba_debug_time_sweep(svi_ba* ba, int reps, double* ms_avg)
+{
+    if (!ba || !ms_avg || reps < 1) return fail(SVI_ERR_INVALID, "bad argument");
+    if (!ba->initialized) return fail(SVI_ERR_STATE, "debug tap before svi_ba_initialize");
+    SVI_HIP(hipSetDevice(ba->opt.device));
+    hipEvent_t a, b;
+    SVI_HIP(hipEventCreate(&a));
+    SVI_HIP(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) { ba_linearize_lm(ba->d, ba->cur, ba->stream); ba_linearize_pose(ba->d, ba->cur, ba->stream); }
+    SVI_HIP(hipEventRecord(a, ba->stream));
+    for (int i = 0; i < reps; ++i) { ba_linearize_lm(ba->d, ba->cur, ba->stream); ba_linearize_pose(ba->d, ba->cur, ba->stream); }
+    SVI_HIP(hipEventRecord(b, ba->stream));
+    SVI_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    SVI_HIP(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    *ms_avg = (double)ms / reps;
     return SVI_OK;
 }
 

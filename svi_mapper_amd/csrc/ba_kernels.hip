@@ -63,13 +63,16 @@ struct EdgeIn {
     bool   robust;
 };
 
-__device__ __forceinline__ void load_edge(const double* __restrict__ zp, const double* __restrict__ ip, int planes,
+// DIAG: every information matrix of the graph is diagonal (the reference only sets diagonals,
+// Cg2oOptimizer.cpp:1014,1038,1066): 3 planes are stored and the off-diagonal terms fold away at compile time
+template <bool DIAG>
+__device__ __forceinline__ void load_edge(const double* __restrict__ zp, const double* __restrict__ ip,
                                           const uint8_t* __restrict__ flags, int E, int e, EdgeIn& in)
 {
     in.z[0] = zp[e]; in.z[1] = zp[E + e]; in.z[2] = zp[2 * E + e];
-    if (planes == 3) {
+    if (DIAG) {
         in.info[0] = ip[e]; in.info[3] = ip[E + e]; in.info[5] = ip[2 * E + e];
-        in.info[1] = in.info[2] = in.info[4] = 0.0;
+        in.info[1] = 0.0; in.info[2] = 0.0; in.info[4] = 0.0;
     } else {
 #pragma unroll
         for (int k = 0; k < 6; ++k) in.info[k] = ip[k * E + e];
@@ -87,9 +90,12 @@ __device__ __forceinline__ double edge_chi2(const EdgeIn& in, const double* e)
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2: landmark-major Jacobian sweep.  One lane per edge, one workgroup per run of whole landmarks.
-// Writes H_pl (18 planes), H_ll (6 planes), b_l (3 planes); per-workgroup partial chi2 / max diag.
+// K2: landmark-major Jacobian sweep.  One lane per edge, one workgroup per run of whole landmarks
+// (<= 256 edges).  Uses the structured form of ba_math.h (J = A [-I | 2[Z]x | R']): per edge it
+// stores N = A'(rho1 Omega)A R' and Z (12 planes, fully coalesced) instead of the 6x3 block H_pl,
+// and sums H_ll = sum R N, b_l = -sum R u per landmark in a fixed order through LDS.
 // ---------------------------------------------------------------------------------------------
+template <bool DIAG>
 __global__ __launch_bounds__(kBlock) void k_linearize_lm(BaDev d, int cur)
 {
     __shared__ double s_acc[9][kLmBlockEdges];
@@ -105,108 +111,121 @@ __global__ __launch_bounds__(kBlock) void k_linearize_lm(BaDev d, int cur)
     const int e = e0 + tid;
     if (e < e1) {
         EdgeIn in;
-        load_edge(d.e_z, d.e_info, d.info_planes, d.e_flags, E, e, in);
+        load_edge<DIAG>(d.e_z, d.e_info, d.e_flags, E, e, in);
         const int s = d.e_pose[e], l = d.e_lm[e];
         double R[9], t[3], p[3];
 #pragma unroll
         for (int k = 0; k < 9; ++k) R[k] = pose[12 * s + k];
 #pragma unroll
         for (int k = 0; k < 3; ++k) { t[k] = pose[12 * s + 9 + k]; p[k] = lm[3 * l + k]; }
-        double err[3], J[27];
-        proj_eval(in.type, R, t, p, in.z, d.fx, d.fy, d.cx, d.cy, err, J);
+        double err[3], Z[3], A5[5];
+        proj_core(in.type, R, t, p, in.z, d.fx, d.fy, d.cx, d.cy, err, Z, A5);
         const double c2 = edge_chi2(in, err);
         double w = 1.0, r0 = c2;
         if (in.robust) cauchy(d.cauchy_delta, c2, r0, w);
         part[0] = r0; part[1] = c2;
         const bool lfix = d.lm_fixed[l] != 0;
-        // OJ = (w Omega) J   (3 x 9)
-        double O[6];
+        double O[6], C[6], u[3];
 #pragma unroll
         for (int k = 0; k < 6; ++k) O[k] = w * in.info[k];
-        double OJ[27];
+        proj_cu(A5, O, err, C, u);
+        // N = C R'  (C symmetric: c00 c01 c02 c11 c12 c22)
+        const double Cf[9] = {C[0], C[1], C[2], C[1], C[3], C[4], C[2], C[4], C[5]};
+        double N[9];
 #pragma unroll
-        for (int c = 0; c < 9; ++c) {
-            OJ[c]      = O[0] * J[c] + O[1] * J[9 + c] + O[2] * J[18 + c];
-            OJ[9 + c]  = O[1] * J[c] + O[3] * J[9 + c] + O[4] * J[18 + c];
-            OJ[18 + c] = O[2] * J[c] + O[4] * J[9 + c] + O[5] * J[18 + c];
-        }
-        const double Oe[3] = {O[0] * err[0] + O[1] * err[1] + O[2] * err[2], O[1] * err[0] + O[3] * err[1] + O[4] * err[2],
-                              O[2] * err[0] + O[4] * err[1] + O[5] * err[2]};
-        // H_pl = J_p' OJ_l  (6 x 3)
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int a = 0; a < 6; ++a)
+            for (int c = 0; c < 3; ++c) N[3 * r + c] = Cf[3 * r] * R[3 * c] + Cf[3 * r + 1] * R[3 * c + 1] + Cf[3 * r + 2] * R[3 * c + 2];
 #pragma unroll
-            for (int c = 0; c < 3; ++c) {
-                const double v = J[a] * OJ[6 + c] + J[9 + a] * OJ[15 + c] + J[18 + a] * OJ[24 + c];
-                d.W[(size_t)(3 * a + c) * E + e] = lfix ? 0.0 : v;
-            }
-        // H_ll contribution (upper 00 01 02 11 12 22) and b_l = -J_l' Oe
+        for (int k = 0; k < 9; ++k) d.NZ[(size_t)k * E + e] = lfix ? 0.0 : N[k];
+#pragma unroll
+        for (int k = 0; k < 3; ++k) d.NZ[(size_t)(9 + k) * E + e] = Z[k];
+        // H_ll contribution R N (symmetric, upper 00 01 02 11 12 22) and b_l = -R u
         int k = 0;
 #pragma unroll
         for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int c = a; c < 3; ++c, ++k)
-                s_acc[k][tid] = J[6 + a] * OJ[6 + c] + J[15 + a] * OJ[15 + c] + J[24 + a] * OJ[24 + c];
+            for (int c = a; c < 3; ++c, ++k) s_acc[k][tid] = R[3 * a] * N[c] + R[3 * a + 1] * N[3 + c] + R[3 * a + 2] * N[6 + c];
 #pragma unroll
-        for (int c = 0; c < 3; ++c) s_acc[6 + c][tid] = -(J[6 + c] * Oe[0] + J[15 + c] * Oe[1] + J[24 + c] * Oe[2]);
+        for (int a = 0; a < 3; ++a) s_acc[6 + a][tid] = -(R[3 * a] * u[0] + R[3 * a + 1] * u[1] + R[3 * a + 2] * u[2]);
     }
     __syncthreads();
+    // per-landmark sums, one (landmark, value) pair per lane: fixed order over the landmark's edges
     double mx = 0.0;
-    const int l = l0 + tid;
-    if (l < l1) {
-        double acc[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
-        const int a0 = d.lm_ptr[l] - e0, a1 = d.lm_ptr[l + 1] - e0;
-        for (int a = a0; a < a1; ++a) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) acc[k] += s_acc[k][a];
-        }
-        // landmark-closure priors (EdgePointXYZ with a fixed partner, Cg2oOptimizer.cpp:448-458)
-        for (int q = d.lm_ll_ptr[l]; q < d.lm_ll_ptr[l + 1]; ++q) {
-            double ee[3], O[6];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) ee[k] = lm[3 * l + k] - d.ll_ref[3 * q + k] - d.ll_z[3 * q + k];
-#pragma unroll
-            for (int k = 0; k < 6; ++k) O[k] = d.ll_info[6 * q + k];
-            const double c2 = ee[0] * (O[0] * ee[0] + 2.0 * (O[1] * ee[1] + O[2] * ee[2])) +
-                              ee[1] * (O[3] * ee[1] + 2.0 * O[4] * ee[2]) + ee[2] * O[5] * ee[2];
-            double w = 1.0, r0 = c2;
-            if (d.ll_robust[q]) cauchy(d.cauchy_delta, c2, r0, w);
-            part[0] += r0; part[1] += c2;
-#pragma unroll
-            for (int k = 0; k < 6; ++k) acc[k] += w * O[k];
-            acc[6] -= w * (O[0] * ee[0] + O[1] * ee[1] + O[2] * ee[2]);
-            acc[7] -= w * (O[1] * ee[0] + O[3] * ee[1] + O[4] * ee[2]);
-            acc[8] -= w * (O[2] * ee[0] + O[4] * ee[1] + O[5] * ee[2]);
-        }
-        if (d.lm_fixed[l]) {
-#pragma unroll
-            for (int k = 0; k < 9; ++k) acc[k] = 0.0;
-        }
-        const int Ll = d.Ll;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) d.Hll[(size_t)k * Ll + l] = acc[k];
-#pragma unroll
-        for (int k = 0; k < 3; ++k) d.bl[(size_t)k * Ll + l] = acc[6 + k];
-        mx = fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5])));
+    const int nl = l1 - l0, Ll = d.Ll;
+    for (int task = tid; task < nl * 9; task += kBlock) {
+        const int li = task / 9, k = task - 9 * li, l = l0 + li;
+        double sum = 0.0;
+        const int a1 = d.lm_ptr[l + 1] - e0;
+        for (int a = d.lm_ptr[l] - e0; a < a1; ++a) sum += s_acc[k][a];
+        if (d.lm_fixed[l]) sum = 0.0;
+        if (k < 6) d.Hll[(size_t)k * Ll + l] = sum; else d.bl[(size_t)(k - 6) * Ll + l] = sum;
+        if (k == 0 || k == 3 || k == 5) mx = fmax(mx, fabs(sum));
     }
-    part[2] = 0.0;
-    block_sum<3>(part, s_red);
-    const double bm = block_max(mx, s_red);
-    if (tid == 0) {
-        d.block_part[4 * b + 0] = part[0];
-        d.block_part[4 * b + 1] = part[1];
-        d.block_part[4 * b + 2] = bm;
+    // landmark-closure priors (EdgePointXYZ with a fixed partner, Cg2oOptimizer.cpp:448-458): rare, one lane per landmark
+    if (d.n_lmlm > 0) {
+        __syncthreads();
+        const int l = l0 + tid;
+        if (l < l1 && d.lm_ll_ptr[l + 1] > d.lm_ll_ptr[l] && !d.lm_fixed[l]) {
+            double acc[9];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) acc[k] = d.Hll[(size_t)k * Ll + l];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) acc[6 + k] = d.bl[(size_t)k * Ll + l];
+            for (int q = d.lm_ll_ptr[l]; q < d.lm_ll_ptr[l + 1]; ++q) {
+                double ee[3], O[6];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) ee[k] = lm[3 * l + k] - d.ll_ref[3 * q + k] - d.ll_z[3 * q + k];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) O[k] = d.ll_info[6 * q + k];
+                const double c2 = ee[0] * (O[0] * ee[0] + 2.0 * (O[1] * ee[1] + O[2] * ee[2])) +
+                                  ee[1] * (O[3] * ee[1] + 2.0 * O[4] * ee[2]) + ee[2] * O[5] * ee[2];
+                double w = 1.0, r0 = c2;
+                if (d.ll_robust[q]) cauchy(d.cauchy_delta, c2, r0, w);
+                part[0] += r0; part[1] += c2;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) acc[k] += w * O[k];
+                acc[6] -= w * (O[0] * ee[0] + O[1] * ee[1] + O[2] * ee[2]);
+                acc[7] -= w * (O[1] * ee[0] + O[3] * ee[1] + O[4] * ee[2]);
+                acc[8] -= w * (O[2] * ee[0] + O[4] * ee[1] + O[5] * ee[2]);
+            }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) d.Hll[(size_t)k * Ll + l] = acc[k];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) d.bl[(size_t)k * Ll + l] = acc[6 + k];
+            mx = fmax(mx, fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5]))));
+        }
+    }
+    // two sums and one max across the workgroup with a single barrier
+    {
+        const int lane = tid & 63, wave = tid >> 6;
+        double x0 = part[0], x1 = part[1], x2 = mx;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            x0 += __shfl_down(x0, off, 64);
+            x1 += __shfl_down(x1, off, 64);
+            x2 = fmax(x2, __shfl_down(x2, off, 64));
+        }
+        if (lane == 0) { s_red[wave] = x0; s_red[4 + wave] = x1; s_red[8 + wave] = x2; }
+        __syncthreads();
+        if (tid == 0) {
+            d.block_part[4 * b + 0] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+            d.block_part[4 * b + 1] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+            d.block_part[4 * b + 2] = fmax(fmax(s_red[8], s_red[9]), fmax(s_red[10], s_red[11]));
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // K3: pose-major Jacobian sweep: one workgroup per chunk of <= kPoseChunk edges of ONE pose.
-// Sums J_p' (rho1 Omega) J_p (21) and -J_p' rho1 Omega e (6) in a fixed order.
+// H_pp = sum [ C , -C K ; K C , -K C K ],  b_p = sum [ u ; K u ],  K = 2[Z]x  (21 + 6 values), summed
+// in a fixed order through a small LDS buffer, nine values per pass.
 // ---------------------------------------------------------------------------------------------
+template <bool DIAG>
 __global__ __launch_bounds__(kBlock) void k_linearize_pose(BaDev d, int cur)
 {
-    __shared__ double s_part[27][kBlock + 1];
-    __shared__ double s_q[27][4];
+    __shared__ double s_part[9][kBlock + 1];
+    __shared__ double s_q[27][8];
     const int c = blockIdx.x, tid = threadIdx.x;
     const int s = d.chunk_pose[c];
     const int e0 = d.chunk_begin[c], e1 = d.chunk_begin[c + 1];
@@ -224,42 +243,60 @@ __global__ __launch_bounds__(kBlock) void k_linearize_pose(BaDev d, int cur)
     for (int k = 0; k < 27; ++k) acc[k] = 0.0;
     for (int e = e0 + tid; e < e1; e += kBlock) {
         EdgeIn in;
-        load_edge(d.pm_z, d.pm_info, d.info_planes, d.pm_flags, E, e, in);
+        load_edge<DIAG>(d.pm_z, d.pm_info, d.pm_flags, E, e, in);
         const int l = d.pm_lm[e];
         const double p[3] = {lm[3 * l], lm[3 * l + 1], lm[3 * l + 2]};
-        double err[3], J[27];
-        proj_eval(in.type, R, t, p, in.z, d.fx, d.fy, d.cx, d.cy, err, J);
+        double err[3], Z[3], A5[5];
+        proj_core(in.type, R, t, p, in.z, d.fx, d.fy, d.cx, d.cy, err, Z, A5);
         double w = 1.0, r0;
         if (in.robust) cauchy(d.cauchy_delta, edge_chi2(in, err), r0, w);
-        double O[6];
+        double O[6], C[6], u[3];
 #pragma unroll
         for (int k = 0; k < 6; ++k) O[k] = w * in.info[k];
-        double OJ[18]; // (w Omega) J_p : 3 x 6
+        proj_cu(A5, O, err, C, u);
+        const double Cf[9] = {C[0], C[1], C[2], C[1], C[3], C[4], C[2], C[4], C[5]};
+        const double z0 = 2.0 * Z[0], z1 = 2.0 * Z[1], z2 = 2.0 * Z[2];
+        // G = C K (3x3), K = [[0,-z2,z1],[z2,0,-z0],[-z1,z0,0]]
+        double G[9];
 #pragma unroll
-        for (int a = 0; a < 6; ++a) {
-            OJ[a]      = O[0] * J[a] + O[1] * J[9 + a] + O[2] * J[18 + a];
-            OJ[6 + a]  = O[1] * J[a] + O[3] * J[9 + a] + O[4] * J[18 + a];
-            OJ[12 + a] = O[2] * J[a] + O[4] * J[9 + a] + O[5] * J[18 + a];
+        for (int r = 0; r < 3; ++r) {
+            G[3 * r]     = Cf[3 * r + 1] * z2 - Cf[3 * r + 2] * z1;
+            G[3 * r + 1] = Cf[3 * r + 2] * z0 - Cf[3 * r] * z2;
+            G[3 * r + 2] = Cf[3 * r] * z1 - Cf[3 * r + 1] * z0;
         }
-        int k = 0;
-#pragma unroll
-        for (int a = 0; a < 6; ++a)
-#pragma unroll
-            for (int b = a; b < 6; ++b, ++k) acc[k] += J[a] * OJ[b] + J[9 + a] * OJ[6 + b] + J[18 + a] * OJ[12 + b];
-#pragma unroll
-        for (int a = 0; a < 6; ++a) acc[21 + a] -= OJ[a] * err[0] + OJ[6 + a] * err[1] + OJ[12 + a] * err[2];
+        // Q = K' G = -K G (symmetric 3x3): rows of K times G
+        const double q00 = -(-z2 * G[3] + z1 * G[6]), q01 = -(-z2 * G[4] + z1 * G[7]), q02 = -(-z2 * G[5] + z1 * G[8]);
+        const double q11 = -(z2 * G[1] - z0 * G[7]), q12 = -(z2 * G[2] - z0 * G[8]);
+        const double q22 = -(-z1 * G[2] + z0 * G[5]);
+        // upper triangle of the 6x6, row-major: rows 0-2 = [C | -G], rows 3-5 = [. | Q]
+        acc[0] += C[0];  acc[1] += C[1];  acc[2] += C[2];  acc[3] -= G[0];  acc[4] -= G[1];  acc[5] -= G[2];
+        acc[6] += C[3];  acc[7] += C[4];  acc[8] -= G[3];  acc[9] -= G[4];  acc[10] -= G[5];
+        acc[11] += C[5]; acc[12] -= G[6]; acc[13] -= G[7]; acc[14] -= G[8];
+        acc[15] += q00;  acc[16] += q01;  acc[17] += q02;
+        acc[18] += q11;  acc[19] += q12;
+        acc[20] += q22;
+        // b_p = [ u ; K u ]
+        acc[21] += u[0]; acc[22] += u[1]; acc[23] += u[2];
+        acc[24] += -z2 * u[1] + z1 * u[2];
+        acc[25] += z2 * u[0] - z0 * u[2];
+        acc[26] += -z1 * u[0] + z0 * u[1];
     }
 #pragma unroll
-    for (int k = 0; k < 27; ++k) s_part[k][tid] = acc[k];
-    __syncthreads();
-    if (tid < 27 * 4) {
-        const int k = tid >> 2, q = tid & 3;
-        double sum = 0.0;
-        for (int i = 0; i < 64; ++i) sum += s_part[k][q * 64 + i];
-        s_q[k][q] = sum;
+    for (int pass = 0; pass < 3; ++pass) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) s_part[k][tid] = acc[9 * pass + k];
+        __syncthreads();
+        if (tid < 9 * 8) {
+            const int k = tid >> 3, q = tid & 7;
+            double sum = 0.0;
+#pragma unroll 8
+            for (int i = 0; i < 32; ++i) sum += s_part[k][q * 32 + i];
+            s_q[9 * pass + k][q] = sum;
+        }
+        __syncthreads();
     }
-    __syncthreads();
-    if (tid < 27) d.chunk_out[(size_t)27 * c + tid] = (s_q[tid][0] + s_q[tid][1]) + (s_q[tid][2] + s_q[tid][3]);
+    if (tid < 27)
+        d.chunk_out[(size_t)27 * c + tid] = ((s_q[tid][0] + s_q[tid][1]) + (s_q[tid][2] + s_q[tid][3])) + ((s_q[tid][4] + s_q[tid][5]) + (s_q[tid][6] + s_q[tid][7]));
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -455,11 +492,12 @@ __global__ __launch_bounds__(kBlock) void k_invert_landmarks(BaDev d, double lam
 // right-hand side  g_i += (W_a Hinv_l) b_l.
 // ---------------------------------------------------------------------------------------------
 constexpr int kSchurBatch = 4;             // items staged per wave and pass
-constexpr int kSchurSlot  = 16 * 18 + 12;  // doubles per staged item: 16 edge slots x H_pl(18), Hinv(6), b_l(3), pad
+constexpr int kSchurSlot  = 16 * 12 + 12;  // doubles per staged item: 16 edge slots x (N 9, Z 3), then Hinv(6), b_l(3), pad
 
-struct SchurStage { double v[kSchurBatch][5]; double hv[kSchurBatch]; };
+struct SchurStage { double v[kSchurBatch][3]; double hv[kSchurBatch]; };
 
-// issue the global loads of the items [base, base+nb) of a job (staging role: edge slot es, planes pg, pg+4, ...)
+// issue the global loads of the items [base, base+nb) of a job.  Staging role of a lane: edge slot es
+// (0..7 row segment, 8..15 column segment) and planes pg, pg+4, pg+8 of the 12 (N, Z) planes.
 __device__ __forceinline__ void schur_fetch(const BaDev& d, const int4* __restrict__ items, int base, int nb, bool diag, int lane,
                                             SchurStage& st)
 {
@@ -475,10 +513,7 @@ __device__ __forceinline__ void schur_fetch(const BaDev& d, const int4* __restri
             if (es < 8) { if (es < nI) e = (long long)pk.y + es; }
             else if (es - 8 < nJ) e = (long long)pk.z + (es - 8);
 #pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const int p = pg + 4 * q;
-                st.v[t][q] = (e >= 0 && p < 18) ? d.W[(size_t)p * E + (size_t)e] : 0.0;
-            }
+            for (int q = 0; q < 3; ++q) st.v[t][q] = (e >= 0) ? d.NZ[(size_t)(pg + 4 * q) * E + (size_t)e] : 0.0;
             st.hv[t] = (lane < 6) ? d.Hinv[(size_t)lane * Ll + pk.x] : ((lane < 9) ? d.bl[(size_t)(lane - 6) * Ll + pk.x] : 0.0);
         }
     }
@@ -491,11 +526,8 @@ __device__ __forceinline__ void schur_stash(const SchurStage& st, int nb, int la
     for (int t = 0; t < kSchurBatch; ++t) {
         if (t < nb) {
 #pragma unroll
-            for (int q = 0; q < 5; ++q) {
-                const int p = pg + 4 * q;
-                if (p < 18) slots[t][es * 18 + p] = st.v[t][q];
-            }
-            if (lane < 9) slots[t][288 + lane] = st.hv[t];
+            for (int q = 0; q < 3; ++q) slots[t][es * 12 + pg + 4 * q] = st.v[t][q];
+            if (lane < 9) slots[t][192 + lane] = st.hv[t];
         }
     }
 }
@@ -504,6 +536,8 @@ __global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
 {
     // The operands of kSchurBatch items are staged in a wave-private LDS region, double buffered: the
     // global loads of batch k+1 are in flight while batch k is being multiplied out of LDS.
+    // Block of pose pair (a,b) for one landmark, with M = N_a Hinv N_b' (3x3), Ka = 2[Z_a]x, Kb = 2[Z_b]x:
+    //     H_pl,a Hinv H_pl,b' = [ M , -M Kb ; Ka M , -Ka M Kb ]
     __shared__ double s_stage[kBlock / 64][2][kSchurBatch][kSchurSlot];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int job = blockIdx.x * (kBlock / 64) + wave; // wave-uniform: item records come through the scalar cache
@@ -539,26 +573,59 @@ __global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
             const bool active = ((mI >> i) & 1u) && ((mJ >> j) & 1u) && (!diag || i >= j);
             if (!active) continue;
             const double* slot = s_stage[wave][buf][t];
-            const double* wa = slot + 18 * __popc(mI & below_i);
-            const double* wb = slot + 18 * (diag ? __popc(mJ & below_j) : 8 + __popc(mJ & below_j));
-            const double* Hi = slot + 288;
-            double T[18]; // W_a Hinv
+            const double* na = slot + 12 * __popc(mI & below_i);
+            const double* nbp = slot + 12 * (diag ? __popc(mJ & below_j) : 8 + __popc(mJ & below_j));
+            const double* Hi = slot + 192;
+            double T[9]; // N_a Hinv
 #pragma unroll
-            for (int r = 0; r < 6; ++r) {
-                const double w0 = wa[3 * r], w1 = wa[3 * r + 1], w2 = wa[3 * r + 2];
+            for (int r = 0; r < 3; ++r) {
+                const double w0 = na[3 * r], w1 = na[3 * r + 1], w2 = na[3 * r + 2];
                 T[3 * r]     = w0 * Hi[0] + w1 * Hi[1] + w2 * Hi[2];
                 T[3 * r + 1] = w0 * Hi[1] + w1 * Hi[3] + w2 * Hi[4];
                 T[3 * r + 2] = w0 * Hi[2] + w1 * Hi[4] + w2 * Hi[5];
             }
+            double M[9]; // T N_b'
 #pragma unroll
-            for (int c = 0; c < 6; ++c) {
-                const double w0 = wb[3 * c], w1 = wb[3 * c + 1], w2 = wb[3 * c + 2];
+            for (int c = 0; c < 3; ++c) {
+                const double w0 = nbp[3 * c], w1 = nbp[3 * c + 1], w2 = nbp[3 * c + 2];
 #pragma unroll
-                for (int r = 0; r < 6; ++r) acc[6 * r + c] += T[3 * r] * w0 + T[3 * r + 1] * w1 + T[3 * r + 2] * w2;
+                for (int r = 0; r < 3; ++r) M[3 * r + c] = T[3 * r] * w0 + T[3 * r + 1] * w1 + T[3 * r + 2] * w2;
             }
-            if (diag && i == j) {
+            const double a0 = 2.0 * na[9], a1 = 2.0 * na[10], a2 = 2.0 * na[11];
+            const double b0 = 2.0 * nbp[9], b1 = 2.0 * nbp[10], b2 = 2.0 * nbp[11];
+            // KM = Ka M
+            double KM[9];
 #pragma unroll
-                for (int r = 0; r < 6; ++r) gacc[r] += T[3 * r] * Hi[6] + T[3 * r + 1] * Hi[7] + T[3 * r + 2] * Hi[8];
+            for (int c = 0; c < 3; ++c) {
+                KM[c]     = -a2 * M[3 + c] + a1 * M[6 + c];
+                KM[3 + c] = a2 * M[c] - a0 * M[6 + c];
+                KM[6 + c] = -a1 * M[c] + a0 * M[3 + c];
+            }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                // top rows: [ M | -M Kb ]
+                acc[6 * r]     += M[3 * r];
+                acc[6 * r + 1] += M[3 * r + 1];
+                acc[6 * r + 2] += M[3 * r + 2];
+                acc[6 * r + 3] -= M[3 * r + 1] * b2 - M[3 * r + 2] * b1;
+                acc[6 * r + 4] -= M[3 * r + 2] * b0 - M[3 * r] * b2;
+                acc[6 * r + 5] -= M[3 * r] * b1 - M[3 * r + 1] * b0;
+                // bottom rows: [ Ka M | -Ka M Kb ]
+                acc[6 * (3 + r)]     += KM[3 * r];
+                acc[6 * (3 + r) + 1] += KM[3 * r + 1];
+                acc[6 * (3 + r) + 2] += KM[3 * r + 2];
+                acc[6 * (3 + r) + 3] -= KM[3 * r + 1] * b2 - KM[3 * r + 2] * b1;
+                acc[6 * (3 + r) + 4] -= KM[3 * r + 2] * b0 - KM[3 * r] * b2;
+                acc[6 * (3 + r) + 5] -= KM[3 * r] * b1 - KM[3 * r + 1] * b0;
+            }
+            if (diag && i == j) { // g_a += H_pl,a Hinv b_l = [ -w ; -Ka w ],  w = T b_l
+                const double w0 = T[0] * Hi[6] + T[1] * Hi[7] + T[2] * Hi[8];
+                const double w1 = T[3] * Hi[6] + T[4] * Hi[7] + T[5] * Hi[8];
+                const double w2 = T[6] * Hi[6] + T[7] * Hi[7] + T[8] * Hi[8];
+                gacc[0] -= w0; gacc[1] -= w1; gacc[2] -= w2;
+                gacc[3] -= -a2 * w1 + a1 * w2;
+                gacc[4] -= a2 * w0 - a0 * w2;
+                gacc[5] -= -a1 * w0 + a0 * w1;
             }
         }
         // the buffer written two iterations from now is this one: every lane is past its reads by then
@@ -665,7 +732,7 @@ __global__ __launch_bounds__(kBlock) void k_update_poses(BaDev d, int cur, doubl
 // landmark part of computeScale, then the error sweep of the trial state.  Same workgroup shape as K2.
 // BACKSUB = false: plain chi2 sweep of state `cur`.
 // ---------------------------------------------------------------------------------------------
-template <bool BACKSUB>
+template <bool BACKSUB, bool DIAG>
 __global__ __launch_bounds__(kBlock) void k_backsub_chi2(BaDev d, int cur, double lambda)
 {
     __shared__ double s_v[3][kLmBlockEdges];
@@ -685,13 +752,15 @@ __global__ __launch_bounds__(kBlock) void k_backsub_chi2(BaDev d, int cur, doubl
         if (e < e1) {
             const int r = d.pose_red[s];
             double v[3] = {0.0, 0.0, 0.0};
-            if (r >= 0) {
+            if (r >= 0) { // H_pl' dx = N' ( -dt + 2 Z x dq )
+                const double z0 = 2.0 * d.NZ[(size_t)9 * E + e], z1 = 2.0 * d.NZ[(size_t)10 * E + e], z2 = 2.0 * d.NZ[(size_t)11 * E + e];
+                const double* dxp = d.dx + 6 * r;
+                const double u0 = -dxp[0] + (z1 * dxp[5] - z2 * dxp[4]);
+                const double u1 = -dxp[1] + (z2 * dxp[3] - z0 * dxp[5]);
+                const double u2 = -dxp[2] + (z0 * dxp[4] - z1 * dxp[3]);
 #pragma unroll
-                for (int i = 0; i < 6; ++i) {
-                    const double dxi = d.dx[6 * r + i];
-#pragma unroll
-                    for (int c = 0; c < 3; ++c) v[c] += d.W[(size_t)(3 * i + c) * E + e] * dxi;
-                }
+                for (int c = 0; c < 3; ++c)
+                    v[c] = d.NZ[(size_t)c * E + e] * u0 + d.NZ[(size_t)(3 + c) * E + e] * u1 + d.NZ[(size_t)(6 + c) * E + e] * u2;
             }
             s_v[0][tid] = v[0]; s_v[1][tid] = v[1]; s_v[2][tid] = v[2];
         }
@@ -737,7 +806,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub_chi2(BaDev d, int cur, doubl
     __syncthreads();
     if (e < e1) {
         EdgeIn in;
-        load_edge(d.e_z, d.e_info, d.info_planes, d.e_flags, (int)E, e, in);
+        load_edge<DIAG>(d.e_z, d.e_info, d.e_flags, (int)E, e, in);
         const int ll = d.e_lm[e] - l0;
         double R[9], t[3];
 #pragma unroll
@@ -784,7 +853,8 @@ __global__ __launch_bounds__(kBlock) void k_debug_jacobians(BaDev d, int cur, co
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= d.E) return;
     EdgeIn in;
-    load_edge(d.e_z, d.e_info, d.info_planes, d.e_flags, d.E, e, in);
+    if (d.info_planes == 3) load_edge<true>(d.e_z, d.e_info, d.e_flags, d.E, e, in);
+    else load_edge<false>(d.e_z, d.e_info, d.e_flags, d.E, e, in);
     const int s = d.e_pose[e], l = d.e_lm[e];
     const double* pose = d.pose[cur];
     const double* lm = d.lm[cur];
@@ -807,11 +877,15 @@ static inline hipStream_t S_(void* st) { return static_cast<hipStream_t>(st); }
 
 void ba_linearize_lm(const BaDev& d, int cur, void* st)
 {
-    if (d.n_lm_blocks > 0) hipLaunchKernelGGL(k_linearize_lm, dim3(d.n_lm_blocks), dim3(kBlock), 0, S_(st), d, cur);
+    if (d.n_lm_blocks <= 0) return;
+    if (d.info_planes == 3) hipLaunchKernelGGL(k_linearize_lm<true>, dim3(d.n_lm_blocks), dim3(kBlock), 0, S_(st), d, cur);
+    else hipLaunchKernelGGL(k_linearize_lm<false>, dim3(d.n_lm_blocks), dim3(kBlock), 0, S_(st), d, cur);
 }
 void ba_linearize_pose(const BaDev& d, int cur, void* st)
 {
-    if (d.n_chunks > 0) hipLaunchKernelGGL(k_linearize_pose, dim3(d.n_chunks), dim3(kBlock), 0, S_(st), d, cur);
+    if (d.n_chunks <= 0) return;
+    if (d.info_planes == 3) hipLaunchKernelGGL(k_linearize_pose<true>, dim3(d.n_chunks), dim3(kBlock), 0, S_(st), d, cur);
+    else hipLaunchKernelGGL(k_linearize_pose<false>, dim3(d.n_chunks), dim3(kBlock), 0, S_(st), d, cur);
 }
 void ba_linearize_aux(const BaDev& d, int cur, int, void* st)
 {
@@ -848,11 +922,15 @@ void ba_update_poses(const BaDev& d, int cur, double lambda, void* st)
 }
 void ba_backsub_chi2(const BaDev& d, int cur, double lambda, void* st)
 {
-    if (d.n_lm_blocks > 0) hipLaunchKernelGGL((k_backsub_chi2<true>), dim3(d.n_lm_blocks), dim3(kBlock), 0, S_(st), d, cur, lambda);
+    if (d.n_lm_blocks <= 0) return;
+    if (d.info_planes == 3) hipLaunchKernelGGL((k_backsub_chi2<true, true>), dim3(d.n_lm_blocks), dim3(kBlock), 0, S_(st), d, cur, lambda);
+    else hipLaunchKernelGGL((k_backsub_chi2<true, false>), dim3(d.n_lm_blocks), dim3(kBlock), 0, S_(st), d, cur, lambda);
 }
 void ba_chi2_only(const BaDev& d, int which, void* st)
 {
-    if (d.n_lm_blocks > 0) hipLaunchKernelGGL((k_backsub_chi2<false>), dim3(d.n_lm_blocks), dim3(kBlock), 0, S_(st), d, which, 0.0);
+    if (d.n_lm_blocks <= 0) return;
+    if (d.info_planes == 3) hipLaunchKernelGGL((k_backsub_chi2<false, true>), dim3(d.n_lm_blocks), dim3(kBlock), 0, S_(st), d, which, 0.0);
+    else hipLaunchKernelGGL((k_backsub_chi2<false, false>), dim3(d.n_lm_blocks), dim3(kBlock), 0, S_(st), d, which, 0.0);
 }
 void ba_reduce_trial_scalars(const BaDev& d, void* st)
 {

@@ -80,6 +80,59 @@ SVI_HD void proj_eval(int type, const double* R, const double* t, const double* 
     }
 }
 
+// Structured form of the three projection edges (EdgeSE3PointXYZ / ...Depth / ...Disparity):
+//     J_pose = A [ -I | 2[Z]x ],   J_lm = A R'      with  Z = R'(p - t)  and  A = d e / d Z  (3x3)
+// A is the identity for XYZ and has 5 non-zeros for the two projective kinds (rows 0,1: perspective
+// division of K Z, row 2: depth p_z or inverse depth 1/p_z).  Everything downstream (H blocks, Schur
+// products, back-substitution) is expressed through  C = A' (rho1 Omega) A  (symmetric 3x3),
+// u = A' (rho1 Omega) e,  N = C R'  and Z:
+//     H_pl = [ -N ; -2[Z]x N ]          H_ll = R N            b_l = -R u
+//     H_pp = [ C , -C K ; K C , -K C K ] with K = 2[Z]x       b_p = [ u ; K u ]
+// A is returned as (a00, a02, a11, a12, a22): a01 = a10 = a20 = a21 = 0.
+SVI_HD void proj_core(int type, const double* R, const double* t, const double* p, const double* z, double fx,
+                      double fy, double cx, double cy, double* e, double* Z, double* A5)
+{
+    to_camera(R, t, p, Z);
+    if (type == 0) {
+        e[0] = Z[0] - z[0]; e[1] = Z[1] - z[1]; e[2] = Z[2] - z[2];
+        A5[0] = 1.0; A5[1] = 0.0; A5[2] = 1.0; A5[3] = 0.0; A5[4] = 1.0;
+        return;
+    }
+    const double pz = Z[2], iz = 1.0 / pz, iz2 = iz * iz;
+    const double px = fx * Z[0] + cx * pz, py = fy * Z[1] + cy * pz;
+    e[0] = px * iz - z[0];
+    e[1] = py * iz - z[1];
+    e[2] = (type == 1 ? pz : iz) - z[2];
+    A5[0] = fx * iz;  A5[1] = -fx * Z[0] * iz2;
+    A5[2] = fy * iz;  A5[3] = -fy * Z[1] * iz2;
+    A5[4] = (type == 1) ? 1.0 : -iz2;
+}
+
+// C = A' O A (upper: c00 c01 c02 c11 c12 c22) and u = A' O e for O symmetric (upper o00 o01 o02 o11 o12 o22)
+SVI_HD void proj_cu(const double* A5, const double* O, const double* e, double* C, double* u)
+{
+    const double a00 = A5[0], a02 = A5[1], a11 = A5[2], a12 = A5[3], a22 = A5[4];
+    // OA = O A : columns of A are (a00,0,0), (0,a11,0), (a02,a12,a22)
+    const double oa00 = O[0] * a00, oa10 = O[1] * a00, oa20 = O[2] * a00;
+    const double oa01 = O[1] * a11, oa11 = O[3] * a11, oa21 = O[4] * a11;
+    const double oa02 = O[0] * a02 + O[1] * a12 + O[2] * a22;
+    const double oa12 = O[1] * a02 + O[3] * a12 + O[4] * a22;
+    const double oa22 = O[2] * a02 + O[4] * a12 + O[5] * a22;
+    C[0] = a00 * oa00;                            // c00
+    C[1] = a00 * oa01;                            // c01
+    C[2] = a00 * oa02;                            // c02
+    C[3] = a11 * oa11;                            // c11
+    C[4] = a11 * oa12;                            // c12
+    C[5] = a02 * oa02 + a12 * oa12 + a22 * oa22;  // c22
+    (void)oa10; (void)oa20; (void)oa21;
+    const double oe0 = O[0] * e[0] + O[1] * e[1] + O[2] * e[2];
+    const double oe1 = O[1] * e[0] + O[3] * e[1] + O[4] * e[2];
+    const double oe2 = O[2] * e[0] + O[4] * e[1] + O[5] * e[2];
+    u[0] = a00 * oe0;
+    u[1] = a11 * oe1;
+    u[2] = a02 * oe0 + a12 * oe1 + a22 * oe2;
+}
+
 SVI_HD void quat_to_R(double w, double x, double y, double z, double* R)
 {
     const double tx = 2 * x, ty = 2 * y, tz = 2 * z;
