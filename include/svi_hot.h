@@ -256,8 +256,8 @@ int svi_ba_set_allreduce(svi_ba* ba, svi_allreduce_fn fn, void* user);
 
 /* --- instrumentation ----------------------------------------------------------------------- */
 enum svi_ba_phase {
-    SVI_PH_LINEARIZE_LM   = 0, /* K2+K3: the Jacobian sweep -> H_pl, H_ll, b_l, per-pose H_pp/b_p records */
-    SVI_PH_LINEARIZE_POSE = 1, /* (unused since the pose sums were folded into the sweep)     */
+    SVI_PH_LINEARIZE_LM   = 0, /* K2: landmark-major Jacobian sweep -> N,Z per edge, H_ll, b_l, chi2   */
+    SVI_PH_LINEARIZE_POSE = 1, /* K3: pose-major sweep -> per-pose H_pp / b_p                 */
     SVI_PH_POSE_EDGES     = 2, /* odometry / gravity / landmark-closure edges                 */
     SVI_PH_SCHUR          = 3, /* K4: per-landmark inverse + windowed S, g contributions      */
     SVI_PH_ASSEMBLE       = 4, /* K4b: ordered reduction of the windows into the tile store  */

@@ -33,22 +33,22 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 template <int TS> struct Lds { static constexpr int LD = TS + 2; }; // (TS+2) % 32 == 2: conflict-free ds_read_b64 of MFMA operands
 
 // rows [r0, r0+NR) of a TS x TS row-major global tile -> LDS (row stride LD)
-template <int TS, int NR>
+template <int TS, int NR, int NTHR = kBlock>
 __device__ __forceinline__ void rows_to_lds(const double* __restrict__ g, int r0, double* s)
 {
     constexpr int LD = Lds<TS>::LD;
     const double2* src = reinterpret_cast<const double2*>(g + (size_t)r0 * TS);
-    constexpr int N = NR * TS / 2, IT = (N + kBlock - 1) / kBlock;
+    constexpr int N = NR * TS / 2, IT = (N + NTHR - 1) / NTHR;
     double2 v[IT];
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-        const int i = it * kBlock + threadIdx.x;
-        if (N % kBlock == 0 || i < N) v[it] = src[i];
+        const int i = it * NTHR + threadIdx.x;
+        if (N % NTHR == 0 || i < N) v[it] = src[i];
     }
 #pragma unroll
     for (int it = 0; it < IT; ++it) {
-        const int i = it * kBlock + threadIdx.x;
-        if (N % kBlock == 0 || i < N) {
+        const int i = it * NTHR + threadIdx.x;
+        if (N % NTHR == 0 || i < N) {
             const int r = i / (TS / 2), c = 2 * (i % (TS / 2));
             s[r * LD + c] = v[it].x;
             s[r * LD + c + 1] = v[it].y;
@@ -102,7 +102,7 @@ constexpr int kPotrfThreads = 512;
 template <int TS, int H>
 __device__ __forceinline__ bool potrf_sweep(const double* __restrict__ A, double* __restrict__ Lg, double* sL, double* sX,
                                             double (*s_col)[4][TS], double* s_rs, int k, int n, double lambda, int stop_after,
-                                            double* __restrict__ y)
+                                            double* __restrict__ y, const double* sPre)
 {
     constexpr int NB = TS / 16, LD = Lds<TS>::LD, KB = 4;
     constexpr int NI = (NB - H + 1) / 2; // blocks rows a = H, H+2, ... owned by this half
@@ -117,6 +117,21 @@ __device__ __forceinline__ bool potrf_sweep(const double* __restrict__ A, double
             if (r == c && k * TS + r < n) v += lambda; // g2o setLambda: H_jj += lambda on real rows
             e[i][b] = v;
         }
+    if (sPre) {
+        // pending update of this tile from the previous tile column: A -= L(k,k-1) L(k,k-1)', done here so the
+        // critical path of the factorisation is one launch per tile column (sPre = LDS image of L(k,k-1))
+        for (int m = 0; m < TS; m += 2) {
+            double2 rr[NI > 0 ? NI : 1], cc[NB];
+#pragma unroll
+            for (int i = 0; i < NI; ++i) rr[i] = *reinterpret_cast<const double2*>(sPre + (16 * (2 * i + H) + ty) * LD + m);
+#pragma unroll
+            for (int b = 0; b < NB; ++b) cc[b] = *reinterpret_cast<const double2*>(sPre + (16 * b + tx) * LD + m);
+#pragma unroll
+            for (int i = 0; i < NI; ++i)
+#pragma unroll
+                for (int b = 0; b <= 2 * i + H; ++b) e[i][b] = fma(-rr[i].y, cc[b].y, fma(-rr[i].x, cc[b].x, e[i][b]));
+        }
+    }
     if (stop_after == 5) { if (tid < TS) y[k * TS + tid] = e[0][0]; return true; }
     long long t_clk0 = 0, t_rt0 = 0;
     const int probe = (stop_after >= 6 && stop_after <= 9) ? stop_after : 0;
@@ -226,10 +241,22 @@ __device__ __forceinline__ bool potrf_sweep(const double* __restrict__ A, double
     return true;
 }
 
+// one 48x48 block of S(c) -= L(a) L(b)' by a 512-thread workgroup (defined below)
 template <int TS>
-__global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(const double* __restrict__ S, double* __restrict__ Lt, double* __restrict__ Linv,
-                                                             const double* __restrict__ g, double* __restrict__ y, int tile_id, int k, int n,
-                                                             double lambda, int* status, int stop_after)
+__device__ void gemm_rest_block(double* __restrict__ S, const double* __restrict__ Lt, const int* __restrict__ ua, const int* __restrict__ ub,
+                                const int* __restrict__ uc, const int* __restrict__ urow, int work, int kprev, double* __restrict__ g,
+                                const double* __restrict__ y, double* sm);
+
+// Fused factorisation step for tile column k.  Workgroup 0 is the critical path: it applies the pending
+// update S(k,k) -= L(k,k-1) L(k,k-1)' (and g_k -= L(k,k-1) y_{k-1}) from the previous column, then
+// factorises the tile (potrf + inverse + y_k).  Workgroups 1.. carry the remaining updates of column k-1
+// (everything except that diagonal target), which nothing on the critical path waits for in this launch.
+template <int TS>
+__global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict__ S, double* __restrict__ Lt, double* __restrict__ Linv,
+                                                             double* __restrict__ g, double* __restrict__ y, int tile_id, int k, int n,
+                                                             double lambda, int* status, int stop_after, int pre_tile,
+                                                             const int* __restrict__ ua, const int* __restrict__ ub,
+                                                             const int* __restrict__ uc, const int* __restrict__ urow)
 {
     constexpr int NB = TS / 16, LD = Lds<TS>::LD;
     extern __shared__ __align__(16) double sm[];
@@ -246,13 +273,27 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(const double* __res
     double (*s_T)[16 * 16] = reinterpret_cast<double (*)[16 * 16]>(s_buf);
     const int tid = threadIdx.x;
     if (*status != 0) return;
+    if (blockIdx.x > 0) { gemm_rest_block<TS>(S, Lt, ua, ub, uc, urow, (int)blockIdx.x - 1, k - 1, g, y, sm); return; }
     const double* A = S + (size_t)tile_id * TS * TS;
     double* Lg = Lt + (size_t)tile_id * TS * TS;
     if (tid < TS) s_g[tid] = g[k * TS + tid];
+    const double* sPre = nullptr;
+    if (pre_tile >= 0) { // stage L(k,k-1) in the (still unused) L image; fold in the forward substitution g_k -= L(k,k-1) y_{k-1}
+        rows_to_lds<TS, TS, kPotrfThreads>(Lt + (size_t)pre_tile * TS * TS, 0, sL);
+        if (tid < TS) s_rs[tid] = y[(k - 1) * TS + tid];
+        __syncthreads();
+        if (tid < TS) {
+            double acc = 0.0;
+#pragma unroll 8
+            for (int m = 0; m < TS; ++m) acc = fma(sL[tid * LD + m], s_rs[m], acc);
+            s_g[tid] -= acc;
+        }
+        sPre = sL;
+    }
     const int half = __builtin_amdgcn_readfirstlane(tid >> 8); // wave-uniform
     bool ok;
-    if (half == 0) ok = potrf_sweep<TS, 0>(A, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y);
-    else           ok = potrf_sweep<TS, 1>(A, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y);
+    if (half == 0) ok = potrf_sweep<TS, 0>(A, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y, sPre);
+    else           ok = potrf_sweep<TS, 1>(A, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y, sPre);
     if (!ok) { if (tid == 0) *status = k + 1; return; }
     if (stop_after == 5 || (stop_after >= 6 && stop_after <= 9) || stop_after == 1) return;
     __syncthreads();
@@ -356,35 +397,35 @@ __global__ __launch_bounds__(kBlock) void k_trsm(const double* __restrict__ S, d
 }
 
 // ---------------------------------------------------------------------------------------------
-// update: S(c)[block] -= L(a)[rows] L(b)[cols]' ; diagonal targets also carry g_i -= L_ik y_k
+// update: S(c)[block] -= L(a)[rows] L(b)[cols]' ; diagonal targets also carry g_i -= L_ik y_k.
+// Runs in the extra workgroups (512 threads) of the fused step kernel.
 // ---------------------------------------------------------------------------------------------
 template <int TS>
-__global__ __launch_bounds__(kBlock) void k_gemm_upd(double* __restrict__ S, const double* __restrict__ Lt, const int* __restrict__ ua,
-                                                     const int* __restrict__ ub, const int* __restrict__ uc, const int* __restrict__ urow,
-                                                     int k, double* __restrict__ g, const double* __restrict__ y, const int* status)
+__device__ void gemm_rest_block(double* __restrict__ S, const double* __restrict__ Lt, const int* __restrict__ ua, const int* __restrict__ ub,
+                                const int* __restrict__ uc, const int* __restrict__ urow, int work, int kprev, double* __restrict__ g,
+                                const double* __restrict__ y, double* sm)
 {
     constexpr int LD = Lds<TS>::LD, Q = TS / kOB;
-    extern __shared__ __align__(16) double sm[];
-    if (*status != 0) return;
     double* sA = sm;
     double* sB = sm + kOB * LD;
-    const int u = blockIdx.x / (Q * Q), qq = blockIdx.x % (Q * Q), qr = qq / Q, qc = qq % Q;
+    const int u = work / (Q * Q), qq = work % (Q * Q), qr = qq / Q, qc = qq % Q;
     const int ia = ua[u], ib = ub[u];
-    rows_to_lds<TS, kOB>(Lt + (size_t)ia * TS * TS, kOB * qr, sA);
-    rows_to_lds<TS, kOB>(Lt + (size_t)ib * TS * TS, kOB * qc, sB);
+    rows_to_lds<TS, kOB, kPotrfThreads>(Lt + (size_t)ia * TS * TS, kOB * qr, sA);
+    rows_to_lds<TS, kOB, kPotrfThreads>(Lt + (size_t)ib * TS * TS, kOB * qc, sB);
     __syncthreads();
     double* C = S + (size_t)uc[u] * TS * TS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int st = wave; st < 9; st += 4) {
+    for (int st = wave; st < 9; st += kPotrfThreads / 64) {
         const int r0 = (st / 3) * 16, c0 = (st % 3) * 16;
         const v4f64 acc = mfma_block<TS, LD>(sA, r0, sB, c0);
 #pragma unroll
         for (int q = 0; q < 4; ++q) C[(size_t)(kOB * qr + r0 + (lane >> 4) + 4 * q) * TS + kOB * qc + c0 + (lane & 15)] -= acc[q];
     }
-    if (ia == ib && qc == 0 && threadIdx.x < kOB) { // forward substitution rides along: g_i -= L_ik y_k
-        const int r = threadIdx.x;
+    if (ia == ib && qc == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + kOB) { // forward substitution rides along: g_i -= L_ik y_k
+        const int r = threadIdx.x - 64;
         double acc = 0.0;
-        for (int m = 0; m < TS; ++m) acc += sA[r * LD + m] * y[k * TS + m];
+#pragma unroll 8
+        for (int m = 0; m < TS; ++m) acc = fma(sA[r * LD + m], y[kprev * TS + m], acc);
         g[urow[u] * TS + kOB * qr + r] -= acc;
     }
 }
@@ -466,19 +507,17 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
     if (!attr) {
         // a workgroup asking for more LDS than the CU has faults the queue: refuse instead of launching
         if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv<TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm<TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g) != hipSuccess ||
-            hipFuncSetAttribute(reinterpret_cast<const void*>(k_gemm_upd<TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g) != hipSuccess)
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm<TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g) != hipSuccess)
             return 1;
         attr = true;
     }
     for (int k = 0; k < p.NT; ++k) {
-        hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(1), dim3(kPotrfThreads), lds_p, s, S, Lt, Linv, g, x, p.h_diag_tile[k], k, n, lambda, status, 0);
+        // fused step: workgroup 0 = pending diagonal update + potrf of column k, the others = remaining updates of column k-1
+        const int u0 = k > 0 ? p.h_upd_ptr[k - 1] : 0, nrest = k > 0 ? p.h_upd_ptr[k] - u0 : 0;
+        hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(1 + nrest * Q * Q), dim3(kPotrfThreads), lds_p, s, S, Lt, Linv, g, x, p.h_diag_tile[k], k, n,
+                           lambda, status, 0, p.h_pre_tile[k], p.upd_a + u0, p.upd_b + u0, p.upd_c + u0, p.upd_row + u0);
         const int nt = p.h_col_ptr[k + 1] - p.h_col_ptr[k];
         if (nt > 0) hipLaunchKernelGGL(k_trsm<TS>, dim3(nt * Q * Q), dim3(kBlock), lds_g, s, S, Lt, Linv, p.trsm_tile + p.h_col_ptr[k], k, status);
-        const int nu = p.h_upd_ptr[k + 1] - p.h_upd_ptr[k];
-        if (nu > 0)
-            hipLaunchKernelGGL(k_gemm_upd<TS>, dim3(nu * Q * Q), dim3(kBlock), lds_g, s, S, Lt, p.upd_a + p.h_upd_ptr[k], p.upd_b + p.h_upd_ptr[k],
-                               p.upd_c + p.h_upd_ptr[k], p.upd_row + p.h_upd_ptr[k], k, g, x, status);
     }
     hipLaunchKernelGGL(k_back_solve<TS>, dim3(1), dim3(kBlock), 0, s, Lt, Linv, x, p, status);
     return 0;
@@ -506,9 +545,9 @@ static int potrf_probe(int reps, int stop_after, double* ms_out)
     (void)hipMemset(g, 0, sizeof(double) * TS); (void)hipMemset(st, 0, sizeof(int));
     hipEvent_t a, b;
     (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(1), dim3(kPotrfThreads), lds_p, 0, S, L, X, g, y, 0, 0, TS, 0.0, st, stop_after);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(1), dim3(kPotrfThreads), lds_p, 0, S, L, X, g, y, 0, 0, TS, 0.0, st, stop_after, -1, nullptr, nullptr, nullptr, nullptr);
     (void)hipEventRecord(a, 0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(1), dim3(kPotrfThreads), lds_p, 0, S, L, X, g, y, 0, 0, TS, 0.0, st, stop_after);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(1), dim3(kPotrfThreads), lds_p, 0, S, L, X, g, y, 0, 0, TS, 0.0, st, stop_after, -1, nullptr, nullptr, nullptr, nullptr);
     (void)hipEventRecord(b, 0);
     (void)hipEventSynchronize(b);
     float ms = 0.f;

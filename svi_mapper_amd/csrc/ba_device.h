@@ -143,6 +143,7 @@ struct CholPlan {
     const int* h_col_ptr = nullptr;
     const int* h_upd_ptr = nullptr;
     const int* h_diag_tile = nullptr; // tile id of (k,k)
+    const int* h_pre_tile = nullptr;  // tile id of (k,k-1) whose update of (k,k) is applied by the factorising workgroup, or -1
     const int* diag_tile = nullptr;   // device copy
     // row lists for the triangular solves
     const int* row_ptr = nullptr;     // [NT+1] tiles (k,j), j<k  (device)

@@ -360,6 +360,9 @@ int build_structure(svi_ba* ba)
         for (size_t a = 0; a < rows.size(); ++a)
             for (size_t b = 0; b <= a; ++b) {
                 nz[(size_t)rows[a] * NT + rows[b]] = 1;
+                // the update of the next diagonal tile by its left neighbour is applied by the workgroup that
+                // factorises that tile (ba_chol.hip, fused step): not part of the update lists
+                if (rows[a] == k + 1 && rows[b] == k + 1) continue;
                 upd_i.push_back(rows[a]); upd_j.push_back(rows[b]); upd_k.push_back(k);
             }
     }
@@ -370,7 +373,7 @@ int build_structure(svi_ba* ba)
         for (int i = j; i < NT; ++i)
             if (nz[(size_t)i * NT + j]) { tile_map[(size_t)i * NT + j] = (int)tile_ti.size(); tile_ti.push_back(i); tile_tj.push_back(j); }
     const int n_tiles = (int)tile_ti.size();
-    std::vector<int> trsm_tile, trsm_row, upd_a, upd_b, upd_c, diag_tile(NT), row_ptr(NT + 1, 0), row_tile, row_col;
+    std::vector<int> trsm_tile, trsm_row, upd_a, upd_b, upd_c, diag_tile(NT), pre_tile(NT, -1), row_ptr(NT + 1, 0), row_tile, row_col;
     for (auto& kr : col_rows) { trsm_tile.push_back(tile_map[(size_t)kr.second * NT + kr.first]); trsm_row.push_back(kr.second); }
     for (size_t u = 0; u < upd_i.size(); ++u) {
         upd_a.push_back(tile_map[(size_t)upd_i[u] * NT + upd_k[u]]);
@@ -380,10 +383,11 @@ int build_structure(svi_ba* ba)
     double chol_flops = 0.0;
     for (int k = 0; k < NT; ++k) {
         diag_tile[k] = tile_map[(size_t)k * NT + k];
+        pre_tile[k] = k > 0 ? tile_map[(size_t)k * NT + (k - 1)] : -1;
         row_ptr[k] = (int)row_tile.size();
         for (int j = 0; j < k; ++j) if (tile_map[(size_t)k * NT + j] >= 0) { row_tile.push_back(tile_map[(size_t)k * NT + j]); row_col.push_back(j); }
         const double t3 = (double)TS * TS * TS;
-        chol_flops += t3 / 3.0 + t3 * (h_col_ptr[k + 1] - h_col_ptr[k]) + 2.0 * t3 * (h_upd_ptr[k + 1] - h_upd_ptr[k]);
+        chol_flops += t3 / 3.0 + t3 * (h_col_ptr[k + 1] - h_col_ptr[k]) + 2.0 * t3 * (h_upd_ptr[k + 1] - h_upd_ptr[k]) + (pre_tile[k] >= 0 ? 2.0 * t3 : 0.0);
     }
     row_ptr[NT] = (int)row_tile.size();
 
@@ -561,8 +565,9 @@ int build_structure(svi_ba* ba)
 
     CholPlan& p = ba->plan;
     p.TS = TS; p.NT = NT;
-    ba->h_col_ptr = h_col_ptr; ba->h_upd_ptr = h_upd_ptr; ba->h_diag_tile = diag_tile;
+    ba->h_col_ptr = h_col_ptr; ba->h_upd_ptr = h_upd_ptr; ba->h_diag_tile = diag_tile; ba->h_pre_tile = pre_tile;
     p.h_col_ptr = ba->h_col_ptr.data(); p.h_upd_ptr = ba->h_upd_ptr.data(); p.h_diag_tile = ba->h_diag_tile.data();
+    p.h_pre_tile = ba->h_pre_tile.data();
     SVI_TRY(dev_upload(ba, h_col_ptr, &p.col_ptr));
     SVI_TRY(dev_upload(ba, trsm_tile, &p.trsm_tile));
     SVI_TRY(dev_upload(ba, trsm_row, &p.trsm_row));
