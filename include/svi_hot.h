@@ -122,6 +122,159 @@ int svi_match_triangulate_dev(svi_matcher* m, const uint8_t* q, int nq, const ui
                               int32_t* out_idx, int32_t* out_dist, double* out_xyz, uint8_t* ok);
 
 /* ------------------------------------------------------------------------------------------
+ * Temporal tracking schedule — the per-landmark geometry and decisions that
+ * CFundamentalMatcher::getPoseStereoPosit (:368-733), trackEpipolar (:794-1315), trackManual
+ * (:1366-2019), _getMatchSampleRecursiveU/V (:2142-2334), _getMatch (:2336-2397) and
+ * _addMeasurementToLandmarkLEFT (:2400-2450) run one landmark at a time around the matcher,
+ * restated as batched device passes over ALL active landmarks of a frame.
+ * What stays with the caller: BRIEF extraction and GFTT detection (OpenCV) - the
+ * passes below say WHERE descriptors are needed (plan, samples) and decide on the descriptors the
+ * caller's extractor returns (ragged pools: landmark i owns pool rows [seg[i], seg[i+1])).
+ * All pointers are device pointers unless a comment says host; launches are asynchronous on the
+ * matcher's stream.
+ * ---------------------------------------------------------------------------------------- */
+
+typedef struct svi_track_camera {
+    double P_left[12];   /* CPinholeCamera::m_matProjection LEFT, 3x4 row-major  (CPinholeCamera.h:28-29) */
+    double P_right[12];  /* ... RIGHT */
+    double K_inv[9];     /* m_matIntrinsicPInverse of the LEFT camera, row-major (CPinholeCamera.h:31)   */
+    double width, height;/* m_dWidthPixels / m_dHeightPixels; the FoV gate is rect(28,28,w-56,h-56) (:61) */
+} svi_track_camera;
+
+/* status bits of svi_track_record.status */
+enum {
+    SVI_TRK_FOV_LEFT        = 1 << 0,  /* rounded LEFT projection inside the FoV rect                */
+    SVI_TRK_FOV_RIGHT       = 1 << 1,  /* rounded RIGHT projection inside the FoV rect               */
+    SVI_TRK_EPI_NO_MOTION   = 1 << 2,  /* |t|^2 == 0 for the detection point: no epipolar line (:847) */
+    SVI_TRK_EPI_OUT_OF_SIGHT= 1 << 3,  /* "vertical out of sight" (:880-885)                          */
+    SVI_TRK_EPI_BAD_PROJ    = 1 << 4,  /* "caught bad projection ..." (:908, :937)                    */
+    SVI_TRK_EPI_ZERO_LENGTH = 1 << 5,  /* "zero line length" (:975)                                   */
+    SVI_TRK_EPI_OK          = 1 << 6   /* s3_* fields describe a sampling run                         */
+};
+
+/* One landmark's schedule for one frame (AoS, 168 bytes, written by svi_track_plan_dev). */
+typedef struct svi_track_record {
+    double  xyz_left[3];     /* T_world_to_left * vecPointXYZOptimized                                 (:377) */
+    double  line[3];         /* epipolar coefficients F * vecUVReferenceLEFT                            (:855) */
+    double  s3_start;        /* dUMinimum (s3_axis 0) or dVForUMinimum (s3_axis 1)                 (:984-991) */
+    float   uv_left[2];      /* getProjectionRounded LEFT                                     (:378, :850)    */
+    float   uv_right[2];     /* getProjectionRounded RIGHT                                             (:379) */
+    float   search_range;    /* (1 + motion_scaling) * last disparity                             (:365,:386) */
+    float   s1_roi_left[2];  /* uv_left - 4*size  : top-left of the (8*size+1)^2 stage-1 ROI           (:395) */
+    float   s1_roi_right[2]; /* uv_right - 4*size                                                      (:449) */
+    float   s2_left[4];      /* stage-2 search rectangle LEFT : upper-left (u,v), lower-right (u,v) (:505-506) */
+    float   s2_right[4];     /* ... RIGHT                                                          (:622-623) */
+    float   s2_ext_left[4];  /* rectangle the descriptors are computed in (grown by 4*size, clamped) (:527-530) */
+    float   s2_ext_right[4]; /*                                                                     (:644-647) */
+    int32_t s3_count;        /* uDeltaU or uDeltaV: samples per recursion depth                   (:966-967)  */
+    int32_t s3_axis;         /* 0: sample over U (uDeltaV < uDeltaU), 1: over V                        (:981) */
+    int32_t status;          /* SVI_TRK_* bits                                                                */
+} svi_track_record;
+
+/* Plan: projection, FoV gate, stage-1/2 rectangles and the clipped epipolar segment of every landmark.
+ *   T_world_to_left : host, 12 doubles (R row-major, t)
+ *   dp_T_left_to_world : host, n_dp x 12 doubles - CDetectionPoint::matTransformationLEFTtoWORLD; the
+ *                     fundamental matrix of a detection point is K^-T (R [t]x) K^-1 with (R,t) =
+ *                     T_world_to_left * dp_T (:800-806)
+ *   xyz_world n x 3 f64, kp_size n f32, last_disparity n f32, uv_reference n x 2 f64 (vecUVReferenceLEFT),
+ *   dp_index n i32 (which detection point owns the landmark)
+ *   records  n svi_track_record
+ *   s3_seg   n+1 i32 (nullable): exclusive scan of s3_count over landmarks with SVI_TRK_EPI_OK
+ *   total_samples : host out (nullable); when given the call synchronises the stream. */
+int svi_track_plan_dev(svi_matcher* m, const svi_track_camera* cam, const double* T_world_to_left,
+                       const double* dp_T_left_to_world, int n_dp, double motion_scaling,
+                       const double* xyz_world, const float* kp_size, const float* last_disparity,
+                       const double* uv_reference, const int32_t* dp_index, int n,
+                       svi_track_record* records, int32_t* s3_seg, int64_t* total_samples);
+
+/* Epipolar sampling at recursion depth `depth` (0, then 2 on failure: CFundamentalMatcher.h:84-85):
+ * key points along the clipped line, the ROI the reference cuts around them and the key points in ROI
+ * coordinates (:2154-2227 / :2246-2318).
+ *   sel      : n_sel i32 landmark indices (nullable: identity over all n_sel = n landmarks)
+ *   seg      : n_sel+1 i32 segment starts inside sample_uv (for sel == NULL this is s3_seg of the plan;
+ *              landmarks without SVI_TRK_EPI_OK own empty segments)
+ *   sample_uv: total x 2 f32, key point positions in ROI coordinates (what the extractor is given)
+ *   roi      : n_sel x 4 f32 (fUTopLeft, fVTopLeft, fWidth, fHeigth) */
+int svi_track_epipolar_samples_dev(svi_matcher* m, const svi_track_camera* cam, const svi_track_record* records,
+                                   const float* kp_size, const int32_t* sel, int n_sel, const int32_t* seg,
+                                   int depth, float* sample_uv, float* roi);
+
+/* status of a ragged match / stereo verification */
+enum {
+    SVI_TRK_MATCH_OK             = 0,
+    SVI_TRK_MATCH_EMPTY_POOL     = 1, /* "empty key point pool" / "could not compute descriptors"       */
+    SVI_TRK_MATCH_DISTANCE       = 2, /* best distance >= cut-off                                       */
+    SVI_TRK_MATCH_ORIGINAL       = 3, /* "ORIGINAL matching distance too big" (:2375-2391)              */
+    SVI_TRK_MATCH_RANGE          = 4, /* "insufficient search range" (CTriangulator.cpp:199, :268)      */
+    SVI_TRK_MATCH_DISPARITY      = 5, /* "zero disparity" (CTriangulator.cpp:329)                       */
+    SVI_TRK_MATCH_DEPTH          = 6, /* "invalid depth" (:417, :2426)                                  */
+    SVI_TRK_MATCH_OTHER_MISMATCH = 7, /* "triangulation descriptor mismatch" (:423, :573)               */
+    SVI_TRK_MATCH_SKIPPED        = 8  /* active[i] == 0                                                  */
+};
+
+/* _getMatch batched (:2336-2397): k=1 Hamming NN of q_i inside its own pool segment, first minimum wins,
+ * accepted iff  cutoff_relative > distance  and (original != NULL)  cutoff_original > popcount(original_i ^ winner).
+ *   out_idx : index INSIDE the segment (cv::DMatch::trainIdx) or -1;  out_dist : best distance or 257 for an
+ *   empty pool (reported even when rejected);  out_status : SVI_TRK_MATCH_*;  active nullable (u8). */
+int svi_match_ragged_dev(svi_matcher* m, const uint8_t* q, const uint8_t* original, const uint8_t* active, int nq,
+                         const int32_t* seg, const uint8_t* pool, int cutoff_relative, int cutoff_original,
+                         int32_t* out_idx, int32_t* out_dist, int32_t* out_status);
+
+typedef struct svi_track_stereo_params {
+    double f, cx, cy, duR_flipped, min_disparity; /* CTriangulator::getPointInLEFT (CTriangulator.cpp:326-356) */
+    double depth_min, depth_max;                  /* CTriangulator.cpp:20-21                                    */
+    int    cutoff_match;                          /* 100: CTriangulator.cpp:13; accepted iff cutoff > distance  */
+    int    cutoff_other;                          /* 25 (stage 1) / 50 (stage 2); <0: no check (stage 3)        */
+    int    other_inclusive;                       /* 1: accepted iff distance <= cutoff_other (:423: throws on
+                                                     cutoff < d);  0: accepted iff cutoff_other > distance (:573) */
+    int    search_in_left;                        /* 0: getPointTriangulatedInRIGHT, 1: ...InLEFT               */
+} svi_track_stereo_params;
+
+/* Hand-over from a temporal match to the stereo search: the reference point and the top-left corner every call
+ * site passes to getPointTriangulatedInRIGHT / InLEFT.
+ *   mode 0  stage 1, found in LEFT  (:407-412)  uv_ref = s1_roi_left + (4s,4s);  topleft = (max(0, s1_roi_left.u - range), s1_roi_left.v)
+ *   mode 1  stage 1, found in RIGHT (:460-466)  uv_ref = s1_roi_right + (4s,4s); topleft = s1_roi_right
+ *   mode 2  stage 2, found in LEFT  (:546-562)  p = s2_left.ul + kp - (4s,4s);   v = p.v - 4s;  ok iff 0 <= v;
+ *                                               uv_ref = p;  topleft = (max(0, p.u - range - 4s), v)
+ *   mode 3  stage 2, found in RIGHT (:663-681)  p = s2_right.ul + kp - (4s,4s);  topleft = (max(0, p.u - 4s), v)
+ *   mode 4  stage 3 (:2382-2383, :2413-2424)    uv_ref = kp + roi.(u,v);         topleft = (max(0, uv_ref.u - range - 4s), uv_ref.v - 4s)
+ * kp = pool_uv[seg[w] + idx[w]] is the key point of the winning candidate (modes 2-4), range = record.search_range,
+ * s = kp_size.  sel (nullable) maps row w of seg/idx/roi/outputs to its landmark; ok[w] = 0 when idx[w] < 0 or the
+ * mode's range test fails. */
+int svi_track_handover_dev(svi_matcher* m, int mode, const svi_track_record* records, const float* kp_size,
+                           const int32_t* sel, int n_sel, const int32_t* seg, const float* pool_uv, const int32_t* idx,
+                           const float* roi, float* uv_ref, float* topleft, uint8_t* ok);
+
+/* Candidate key points of CTriangulator::getPointTriangulatedInRIGHT (CTriangulator.cpp:194-211) /
+ * getPointTriangulatedInLEFT (:262-282): every integer pixel column of ONE row.
+ *   range:  seg (n+1 i32) = exclusive scan of uSearchRangeComplete, out_status = SVI_TRK_MATCH_OK / _RANGE /
+ *           _SKIPPED, roi n x 4 f32 = the cv::Rect handed to the extractor (u, v, width, height; :213/:284),
+ *           total (host, nullable; synchronises)
+ *   candidates: pool_uv total x 2 f32 in ROI coordinates: (4s + k, 4s) in RIGHT, (4s + k + 1, 4s) in LEFT
+ *   search_range is read only when search_in_left != 0 (p_fSearchRange). */
+int svi_track_stereo_range_dev(svi_matcher* m, double width, int search_in_left, const float* uv_ref,
+                               const float* topleft, const float* kp_size, const float* search_range,
+                               const uint8_t* active, int n, int32_t* seg, int32_t* out_status, float* roi,
+                               int64_t* total);
+int svi_track_stereo_candidates_dev(svi_matcher* m, int search_in_left, const float* kp_size, int n,
+                                    const int32_t* seg, float* pool_uv);
+
+/* The stereo half of every stage: CTriangulator::getPointTriangulatedInRIGHT/InLEFT (:185-324) on a ragged
+ * pool of row candidates, triangulation, depth gate (:416-419) and the check of the found descriptor against
+ * the landmark's last descriptor of that image (:423 / :573).
+ *   ref       nq x 32  descriptor found in the first image (the match query)
+ *   last_other nq x 32 landmark's last descriptor in the searched image (nullable iff cutoff_other < 0)
+ *   uv_ref    nq x 2 f32 pixel of `ref` in its image
+ *   topleft   nq x 2 f32 (p_fUTopLeft, p_fVTopLeft) of the searched ROI
+ *   seg/pool/pool_uv : ragged candidates; pool_uv total x 2 f32 in ROI coordinates (cv::KeyPoint::pt)
+ *   out_uv_other nq x 2 f32 = pool_uv[idx] + topleft (:110, :244);  out_xyz nq x 3 f64 LEFT camera frame */
+int svi_track_stereo_verify_dev(svi_matcher* m, const svi_track_stereo_params* prm, const uint8_t* ref,
+                                const uint8_t* last_other, const uint8_t* active, const float* uv_ref,
+                                const float* topleft, int nq, const int32_t* seg, const uint8_t* pool,
+                                const float* pool_uv, int32_t* out_idx, int32_t* out_dist, int32_t* out_status,
+                                float* out_uv_other, double* out_xyz);
+
+/* ------------------------------------------------------------------------------------------
  * Bundle adjustment — replaces the g2o::SparseOptimizer m_cOptimizerSparse of Cg2oOptimizer
  * (Cg2oOptimizer.h:80) together with its solver stack (Cg2oOptimizer.cpp:83-89).
  * Vertex ids follow the reference: landmark id = uID, pose id = uID + 1e6 (Cg2oOptimizer.h:83);

@@ -4,6 +4,9 @@ TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and bench.
 cpu_baseline leg.  Nothing under svi_mapper_amd/ may import this module.
 PARITY UNPINNED (see the C file headers and DESIGN.md "Oracle").
 
+The tracking-schedule functions (track_*) restate src/core/CFundamentalMatcher.cpp one landmark at a time
+(oracle_track.c); OracleFundamentalMatcher replays the reference's try/catch cascade around them.
+
 The Python classes deliberately expose the same method names as
 svi_mapper_amd.BundleAdjuster / HammingMatcher so the parity tests drive both alike.
 """
@@ -93,6 +96,16 @@ def load(path=None):
                                          C.c_float, C.c_int, _i32p, _i32p]
     lib.orc_hamming256_pairs.argtypes = [_u8p, _u8p, C.c_int, _i32p]
     lib.orc_triangulate_rectified.argtypes = [C.c_double] * 5 + [_f32p, _f32p, C.c_int, _f64p, _u8p]
+    vp = C.c_void_p
+    lib.orc_track_record_size.restype = C.c_int
+    lib.orc_track_plan.argtypes = [vp, _f64p, _f64p, C.c_int, C.c_double, _f64p, _f32p, _f32p, _f64p, _i32p, C.c_int, vp, _i32p]
+    lib.orc_track_epipolar_samples.argtypes = [vp, vp, _f32p, _i32p, C.c_int, _i32p, C.c_int, _f32p, _f32p]
+    lib.orc_track_stereo_range.argtypes = [C.c_double, C.c_int, _f32p, _f32p, _f32p, _f32p, _u8p, C.c_int, _i32p, _i32p, _f32p]
+    lib.orc_track_stereo_candidates.argtypes = [C.c_int, _f32p, C.c_int, _i32p, _f32p]
+    lib.orc_match_ragged.argtypes = [_u8p, _u8p, _u8p, C.c_int, _i32p, _u8p, C.c_int, C.c_int, _i32p, _i32p, _i32p]
+    lib.orc_track_stereo_verify.argtypes = [vp, _u8p, _u8p, _u8p, _f32p, _f32p, C.c_int, _i32p, _u8p, _f32p, _i32p, _i32p, _i32p,
+                                            _f32p, _f64p]
+    lib.orc_track_handover.argtypes = [C.c_int, vp, _f32p, _i32p, C.c_int, _i32p, _f32p, _i32p, _f32p, _f32p, _f32p, _u8p]
     if path.endswith("liboracle.so"):
         _LIB = lib
     return lib
@@ -390,3 +403,254 @@ class OracleBA:
 
     def prune_diverged(self):
         return self.lib.orc_ba_prune_diverged(self.h)
+
+
+# ------------------------------------------------------------------------------------------------
+# temporal tracking schedule (oracle_track.c)
+# ------------------------------------------------------------------------------------------------
+TRACK_RECORD = np.dtype([("xyz_left", "<f8", 3), ("line", "<f8", 3), ("s3_start", "<f8"), ("uv_left", "<f4", 2), ("uv_right", "<f4", 2),
+                         ("search_range", "<f4"), ("s1_roi_left", "<f4", 2), ("s1_roi_right", "<f4", 2), ("s2_left", "<f4", 4),
+                         ("s2_right", "<f4", 4), ("s2_ext_left", "<f4", 4), ("s2_ext_right", "<f4", 4), ("s3_count", "<i4"),
+                         ("s3_axis", "<i4"), ("status", "<i4")])
+(M_OK, M_EMPTY_POOL, M_DISTANCE, M_ORIGINAL, M_RANGE, M_DISPARITY, M_DEPTH, M_OTHER, M_SKIPPED) = range(9)
+FOV_LEFT, FOV_RIGHT, EPI_NO_MOTION, EPI_OUT_OF_SIGHT, EPI_BAD_PROJ, EPI_ZERO_LENGTH, EPI_OK = 1, 2, 4, 8, 16, 32, 64
+
+
+class _Cam(C.Structure):
+    _fields_ = [("P_left", C.c_double * 12), ("P_right", C.c_double * 12), ("K_inv", C.c_double * 9), ("width", C.c_double),
+                ("height", C.c_double)]
+
+
+class _StereoParams(C.Structure):
+    _fields_ = [("f", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("duR_flipped", C.c_double), ("min_disparity", C.c_double),
+                ("depth_min", C.c_double), ("depth_max", C.c_double), ("cutoff_match", C.c_int), ("cutoff_other", C.c_int),
+                ("other_inclusive", C.c_int), ("search_in_left", C.c_int)]
+
+
+def track_camera(P_left, P_right, K_inv, width, height):
+    c = _Cam()
+    c.P_left[:] = np.asarray(P_left, np.float64).ravel().tolist()
+    c.P_right[:] = np.asarray(P_right, np.float64).ravel().tolist()
+    c.K_inv[:] = np.asarray(K_inv, np.float64).ravel().tolist()
+    c.width, c.height = float(width), float(height)
+    return c
+
+
+def _a(x, dt, shape=None):
+    if x is None:
+        return None
+    x = np.ascontiguousarray(x, dt)
+    return x if shape is None else x.reshape(shape)
+
+
+def track_plan(cam, T_world_to_left, dp_T, motion_scaling, xyz_world, kp_size, last_disparity, uv_reference, dp_index, lib=None):
+    lib = lib or load()
+    assert lib.orc_track_record_size() == TRACK_RECORD.itemsize
+    T = _a(T_world_to_left, np.float64, 12)
+    dp = _a(dp_T, np.float64, (-1, 12))
+    xyz = _a(xyz_world, np.float64, (-1, 3))
+    n = len(xyz)
+    kp, dis, uvr, dpi = _a(kp_size, np.float32), _a(last_disparity, np.float32), _a(uv_reference, np.float64, (-1, 2)), _a(dp_index, np.int32)
+    rec = np.zeros(n, TRACK_RECORD)
+    seg = np.zeros(n + 1, np.int32)
+    lib.orc_track_plan(C.byref(cam), _p(T, _f64p), _p(dp, _f64p), len(dp), float(motion_scaling), _p(xyz, _f64p), _p(kp, _f32p), _p(dis, _f32p),
+                       _p(uvr, _f64p), _p(dpi, _i32p), n, rec.ctypes.data, _p(seg, _i32p))
+    return rec, seg
+
+
+def track_epipolar_samples(cam, rec, kp_size, seg, depth, sel=None, lib=None):
+    lib = lib or load()
+    kp = _a(kp_size, np.float32)
+    sel = _a(sel, np.int32)
+    seg = _a(seg, np.int32)
+    n_sel = len(seg) - 1
+    out = np.zeros((int(seg[-1]), 2), np.float32)
+    roi = np.zeros((n_sel, 4), np.float32)
+    lib.orc_track_epipolar_samples(C.byref(cam), rec.ctypes.data, _p(kp, _f32p), _p(sel, _i32p), n_sel, _p(seg, _i32p), int(depth),
+                                   _p(out, _f32p), _p(roi, _f32p))
+    return out, roi
+
+
+def track_stereo_range(width, in_left, uv_ref, topleft, kp_size, search_range=None, active=None, lib=None):
+    lib = lib or load()
+    uv, tl, kp = _a(uv_ref, np.float32, (-1, 2)), _a(topleft, np.float32, (-1, 2)), _a(kp_size, np.float32)
+    sr, ac = _a(search_range, np.float32), _a(active, np.uint8)
+    n = len(uv)
+    seg, st, roi = np.zeros(n + 1, np.int32), np.zeros(n, np.int32), np.zeros((n, 4), np.float32)
+    lib.orc_track_stereo_range(float(width), int(in_left), _p(uv, _f32p), _p(tl, _f32p), _p(kp, _f32p), _p(sr, _f32p), _p(ac, _u8p), n,
+                               _p(seg, _i32p), _p(st, _i32p), _p(roi, _f32p))
+    return seg, st, roi
+
+
+def track_stereo_candidates(in_left, kp_size, seg, lib=None):
+    lib = lib or load()
+    kp, seg = _a(kp_size, np.float32), _a(seg, np.int32)
+    out = np.zeros((int(seg[-1]), 2), np.float32)
+    lib.orc_track_stereo_candidates(int(in_left), _p(kp, _f32p), len(kp), _p(seg, _i32p), _p(out, _f32p))
+    return out
+
+
+def match_ragged(q, original, seg, pool, cutoff, cutoff_original=257, active=None, lib=None):
+    lib = lib or load()
+    q, orig, pool = _a(q, np.uint8, (-1, 32)), _a(original, np.uint8), _a(pool, np.uint8)
+    seg, ac = _a(seg, np.int32), _a(active, np.uint8)
+    nq = len(q)
+    idx, dist, st = np.zeros(nq, np.int32), np.zeros(nq, np.int32), np.zeros(nq, np.int32)
+    lib.orc_match_ragged(_p(q, _u8p), _p(orig, _u8p), _p(ac, _u8p), nq, _p(seg, _i32p), _p(pool, _u8p), int(cutoff), int(cutoff_original),
+                         _p(idx, _i32p), _p(dist, _i32p), _p(st, _i32p))
+    return idx, dist, st
+
+
+def stereo_params(f, cx, cy, duR_flipped, min_disparity, depth_min, depth_max, cutoff_match, cutoff_other, other_inclusive, in_left):
+    return _StereoParams(f, cx, cy, duR_flipped, min_disparity, depth_min, depth_max, int(cutoff_match), int(cutoff_other),
+                         int(other_inclusive), int(in_left))
+
+
+def track_stereo_verify(prm, ref, last_other, uv_ref, topleft, seg, pool, pool_uv, active=None, lib=None):
+    lib = lib or load()
+    ref, lo, pool = _a(ref, np.uint8, (-1, 32)), _a(last_other, np.uint8), _a(pool, np.uint8)
+    uv, tl, puv = _a(uv_ref, np.float32, (-1, 2)), _a(topleft, np.float32, (-1, 2)), _a(pool_uv, np.float32)
+    seg, ac = _a(seg, np.int32), _a(active, np.uint8)
+    nq = len(ref)
+    idx, dist, st = np.zeros(nq, np.int32), np.zeros(nq, np.int32), np.zeros(nq, np.int32)
+    uvo, xyz = np.zeros((nq, 2), np.float32), np.zeros((nq, 3))
+    lib.orc_track_stereo_verify(C.byref(prm), _p(ref, _u8p), _p(lo, _u8p), _p(ac, _u8p), _p(uv, _f32p), _p(tl, _f32p), nq, _p(seg, _i32p),
+                                _p(pool, _u8p), _p(puv, _f32p), _p(idx, _i32p), _p(dist, _i32p), _p(st, _i32p), _p(uvo, _f32p), _p(xyz, _f64p))
+    return idx, dist, st, uvo, xyz
+
+
+def track_handover(mode, rec, kp_size, sel=None, seg=None, pool_uv=None, idx=None, roi=None, lib=None):
+    lib = lib or load()
+    kp, sel, seg = _a(kp_size, np.float32), _a(sel, np.int32), _a(seg, np.int32)
+    puv, idx, roi = _a(pool_uv, np.float32), _a(idx, np.int32), _a(roi, np.float32)
+    n_sel = len(sel) if sel is not None else len(rec)
+    uv, tl, ok = np.zeros((n_sel, 2), np.float32), np.zeros((n_sel, 2), np.float32), np.zeros(n_sel, np.uint8)
+    lib.orc_track_handover(int(mode), rec.ctypes.data, _p(kp, _f32p), _p(sel, _i32p), n_sel, _p(seg, _i32p), _p(puv, _f32p), _p(idx, _i32p),
+                           _p(roi, _f32p), _p(uv, _f32p), _p(tl, _f32p), _p(ok, _u8p))
+    return uv, tl, ok
+
+
+class NoMatch(Exception):
+    """CExceptionNoMatchFound / CExceptionNoMatchFoundInternal with the status code the batched path reports."""
+
+    def __init__(self, code):
+        super().__init__(code)
+        self.code = code
+
+
+class OracleFundamentalMatcher:
+    """The reference's per-landmark cascade, replayed ONE landmark at a time around the oracle_track.c functions:
+    nested try / except exactly where CFundamentalMatcher.cpp has them.  extractor(side, roi[4], kp_uv[k,2]) ->
+    (kept kp_uv, descriptors) and detector(side, rect[4]) -> kp_uv are host (numpy) callables."""
+
+    def __init__(self, cam, stereo, lib=None):
+        """stereo = dict(f, cx, cy, duR_flipped, min_disparity, depth_min, depth_max, width)"""
+        self.cam, self.st, self.lib = cam, stereo, lib or load()
+
+    # CTriangulator::getPointTriangulatedInRIGHT / InLEFT + the caller's depth / descriptor checks
+    def _stereo(self, extractor, in_left, kp, rng, ref_desc, last_other, uv_ref, topleft, cutoff_other, inclusive):
+        seg, st, roi = track_stereo_range(self.st["width"], in_left, uv_ref[None], topleft[None], [kp], [rng] if in_left else None, lib=self.lib)
+        if st[0] != M_OK:
+            raise NoMatch(int(st[0]))
+        cand = track_stereo_candidates(in_left, [kp], seg, lib=self.lib)
+        kp_uv, desc = extractor("left" if in_left else "right", roi[0], cand)
+        prm = stereo_params(self.st["f"], self.st["cx"], self.st["cy"], self.st["duR_flipped"], self.st["min_disparity"], self.st["depth_min"],
+                            self.st["depth_max"], 100, cutoff_other, inclusive, in_left)
+        seg1 = np.array([0, len(kp_uv)], np.int32)
+        idx, dist, st, uvo, xyz = track_stereo_verify(prm, ref_desc[None], None if last_other is None else last_other[None], uv_ref[None],
+                                                      topleft[None], seg1, desc, kp_uv, lib=self.lib)
+        if st[0] != M_OK:
+            raise NoMatch(int(st[0]))
+        return uvo[0], xyz[0], desc[idx[0]]
+
+    def stage1(self, rec, kp_size, extractor, last_l, last_r):
+        n = len(rec)
+        out = [dict(status=M_SKIPPED) for _ in range(n)]
+        for i in range(n):
+            r = rec[i]
+            if not (r["status"] & FOV_LEFT and r["status"] & FOV_RIGHT):                          # :389
+                continue
+            one = rec[i:i + 1]
+            kp = np.float32(kp_size[i])
+            for side in (0, 1):                                                                   # try LEFT, catch -> RIGHT
+                try:
+                    uv_ref, tl, _ = track_handover(side, one, [kp], lib=self.lib)
+                    roi_xy = r["s1_roi_left" if side == 0 else "s1_roi_right"]
+                    L = np.float32(8) * kp + np.float32(1)
+                    roi = np.array([roi_xy[0], roi_xy[1], L, L], np.float32)
+                    kp_uv, desc = extractor("left" if side == 0 else "right", roi, np.array([[np.float32(4) * kp, np.float32(4) * kp]], np.float32))
+                    here, there = (last_l[i], last_r[i]) if side == 0 else (last_r[i], last_l[i])
+                    idx, dist, st = match_ragged(here[None], None, [0, len(kp_uv)], desc, 25, lib=self.lib)   # 1 == rows && 25 > norm
+                    if st[0] != M_OK:
+                        raise NoMatch(int(st[0]))
+                    uvo, xyz, d_other = self._stereo(extractor, side, kp, r["search_range"], desc[idx[0]], there, uv_ref[0], tl[0], 25, 1)
+                    if side == 0:
+                        out[i] = dict(status=M_OK, uv_left=r["uv_left"].copy(), uv_right=uvo, xyz=xyz, desc_left=desc[idx[0]], desc_right=d_other)
+                    else:
+                        out[i] = dict(status=M_OK, uv_left=uvo, uv_right=r["uv_right"].copy(), xyz=xyz, desc_left=d_other, desc_right=desc[idx[0]])
+                    break
+                except NoMatch as e:
+                    out[i] = dict(status=e.code)
+        return out
+
+    def stage2(self, rec, kp_size, detector, extractor, last_l, last_r):
+        n = len(rec)
+        out = [dict(status=M_SKIPPED) for _ in range(n)]
+        for i in range(n):
+            r = rec[i]
+            if not (r["status"] & FOV_LEFT and r["status"] & FOV_RIGHT):
+                continue
+            one = rec[i:i + 1]
+            kp = np.float32(kp_size[i])
+            for side in (0, 1):
+                name = "left" if side == 0 else "right"
+                try:
+                    found = detector(name, r["s2_" + name])
+                    shifted = (found + np.float32(4) * kp).astype(np.float32)                     # :533
+                    kp_uv, desc = extractor(name, r["s2_ext_" + name], shifted)
+                    here, there = (last_l[i], last_r[i]) if side == 0 else (last_r[i], last_l[i])
+                    seg = np.array([0, len(kp_uv)], np.int32)
+                    idx, dist, st = match_ragged(here[None], None, seg, desc, 50, lib=self.lib)   # :540-545
+                    if st[0] != M_OK:
+                        raise NoMatch(int(st[0]))
+                    uv_ref, tl, ok = track_handover(2 + side, one, [kp], None, seg, kp_uv, idx, lib=self.lib)
+                    if not ok[0]:
+                        raise NoMatch(M_RANGE)                                                    # "out of tracking range"
+                    uvo, xyz, d_other = self._stereo(extractor, side, kp, r["search_range"], desc[idx[0]], there, uv_ref[0], tl[0], 50, 0)
+                    if side == 0:
+                        out[i] = dict(status=M_OK, uv_left=uv_ref[0], uv_right=uvo, xyz=xyz, desc_left=desc[idx[0]], desc_right=d_other)
+                    else:
+                        out[i] = dict(status=M_OK, uv_left=uvo, uv_right=uv_ref[0], xyz=xyz, desc_left=d_other, desc_right=desc[idx[0]])
+                    break
+                except NoMatch as e:
+                    out[i] = dict(status=e.code)
+        return out
+
+    def epipolar(self, rec, kp_size, extractor, last_l, ref_l):
+        n = len(rec)
+        out = [dict(status=M_SKIPPED) for _ in range(n)]
+        for i in range(n):
+            r = rec[i]
+            if not r["status"] & EPI_OK:
+                continue
+            one = rec[i:i + 1]
+            kp = np.float32(kp_size[i])
+            seg = np.array([0, r["s3_count"]], np.int32)
+            try:
+                depth = 0
+                while True:                                                                       # _getMatchSampleRecursiveU/V
+                    samples, roi = track_epipolar_samples(self.cam, one, [kp], seg, depth, lib=self.lib)
+                    kp_uv, desc = extractor("left", roi[0], samples)
+                    seg_e = np.array([0, len(kp_uv)], np.int32)
+                    idx, dist, st = match_ragged(last_l[i][None], ref_l[i][None], seg_e, desc, 50, 100, lib=self.lib)   # _getMatch
+                    if st[0] == M_OK:
+                        break
+                    if depth == 2:                                                                # m_uRecursionLimitEpipolarLines
+                        raise NoMatch(int(st[0]))
+                    depth += 2
+                uv_ref, tl, ok = track_handover(4, one, [kp], None, seg_e, kp_uv, idx, roi, lib=self.lib)
+                uvo, xyz, d_other = self._stereo(extractor, 0, kp, r["search_range"], desc[idx[0]], None, uv_ref[0], tl[0], -1, 0)
+                out[i] = dict(status=M_OK, uv_left=uv_ref[0], uv_right=uvo, xyz=xyz, desc_left=desc[idx[0]], desc_right=d_other)
+            except NoMatch as e:
+                out[i] = dict(status=e.code)
+        return out

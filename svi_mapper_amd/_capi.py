@@ -33,6 +33,33 @@ class Gate(C.Structure):
     _fields_ = [("q_uv", vp), ("t_uv", vp), ("q_umin", vp), ("q_umax", vp), ("v_tol", C.c_float)]
 
 
+class TrackCamera(C.Structure):
+    _fields_ = [("P_left", C.c_double * 12), ("P_right", C.c_double * 12), ("K_inv", C.c_double * 9),
+                ("width", C.c_double), ("height", C.c_double)]
+
+
+class TrackStereoParams(C.Structure):
+    _fields_ = [("f", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("duR_flipped", C.c_double),
+                ("min_disparity", C.c_double), ("depth_min", C.c_double), ("depth_max", C.c_double),
+                ("cutoff_match", C.c_int), ("cutoff_other", C.c_int), ("other_inclusive", C.c_int),
+                ("search_in_left", C.c_int)]
+
+
+# numpy view of svi_track_record (168 bytes, include/svi_hot.h)
+TRACK_RECORD_FIELDS = [("xyz_left", "<f8", 3), ("line", "<f8", 3), ("s3_start", "<f8"), ("uv_left", "<f4", 2),
+                       ("uv_right", "<f4", 2), ("search_range", "<f4"), ("s1_roi_left", "<f4", 2),
+                       ("s1_roi_right", "<f4", 2), ("s2_left", "<f4", 4), ("s2_right", "<f4", 4),
+                       ("s2_ext_left", "<f4", 4), ("s2_ext_right", "<f4", 4), ("s3_count", "<i4"), ("s3_axis", "<i4"),
+                       ("status", "<i4")]
+TRACK_RECORD_SIZE = 168
+
+# SVI_TRK_* status bits / SVI_TRK_MATCH_* codes
+TRK_FOV_LEFT, TRK_FOV_RIGHT, TRK_EPI_NO_MOTION, TRK_EPI_OUT_OF_SIGHT = 1, 2, 4, 8
+TRK_EPI_BAD_PROJ, TRK_EPI_ZERO_LENGTH, TRK_EPI_OK = 16, 32, 64
+(MATCH_OK, MATCH_EMPTY_POOL, MATCH_DISTANCE, MATCH_ORIGINAL, MATCH_RANGE, MATCH_DISPARITY, MATCH_DEPTH,
+ MATCH_OTHER_MISMATCH, MATCH_SKIPPED) = range(9)
+
+
 class BaOptions(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("baseline_m", C.c_double), ("cauchy_delta", C.c_double), ("lm_tau", C.c_double),
@@ -73,6 +100,15 @@ SIGNATURES = {
     "svi_triangulate_rectified_dev": (C.c_int, [vp] + [C.c_double] * 5 + [vp, vp, C.c_int, vp, vp]),
     "svi_match_triangulate_dev": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.POINTER(Gate), C.c_int] +
                                   [C.c_double] * 5 + [vp, vp, vp, vp]),
+    "svi_track_plan_dev": (C.c_int, [vp, C.POINTER(TrackCamera), f64p, f64p, C.c_int, C.c_double, vp, vp, vp, vp, vp, C.c_int,
+                                     vp, vp, i64p]),
+    "svi_track_epipolar_samples_dev": (C.c_int, [vp, C.POINTER(TrackCamera), vp, vp, vp, C.c_int, vp, C.c_int, vp, vp]),
+    "svi_track_handover_dev": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, vp, vp, vp, vp, vp, vp, vp]),
+    "svi_track_stereo_range_dev": (C.c_int, [vp, C.c_double, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, i64p]),
+    "svi_track_stereo_candidates_dev": (C.c_int, [vp, C.c_int, vp, C.c_int, vp, vp]),
+    "svi_match_ragged_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
+    "svi_track_stereo_verify_dev": (C.c_int, [vp, C.POINTER(TrackStereoParams), vp, vp, vp, vp, vp, C.c_int, vp, vp, vp,
+                                              vp, vp, vp, vp, vp]),
     "svi_ba_options_default": (None, [C.POINTER(BaOptions)]),
     "svi_ba_create": (C.c_int, [C.POINTER(BaOptions), C.POINTER(vp)]),
     "svi_ba_destroy": (C.c_int, [vp]),

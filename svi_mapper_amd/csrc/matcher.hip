@@ -22,6 +22,7 @@
 #include <cstdint>
 
 #include "common.h"
+#include "matcher_handle.h"
 
 namespace {
 
@@ -226,14 +227,6 @@ __global__ __launch_bounds__(256) void k_triangulate(const float2* uvL, const fl
 
 } // namespace
 
-struct svi_matcher {
-    int         device = 0;
-    hipStream_t stream = nullptr;
-    bool        own_stream = false;
-    int         n_cu = 256;
-    svi::DevBuf keys;      // split-mode packed minima
-    svi::DevBuf scratch;   // host-pointer entry points stage through here
-};
 
 extern "C" {
 
@@ -263,6 +256,8 @@ int svi_matcher_destroy(svi_matcher* m)
     (void)hipStreamSynchronize(m->stream);
     m->keys.release();
     m->scratch.release();
+    m->track.release();
+    if (m->track_ev) (void)hipEventDestroy(m->track_ev);
     if (m->own_stream) (void)hipStreamDestroy(m->stream);
     delete m;
     return SVI_OK;

@@ -18,7 +18,31 @@ from oracle import oracle as orc  # noqa: E402
 from svi_mapper_amd import synth  # noqa: E402
 
 
+def track_golden():
+    """tests/golden/track_small.npz: the tracking schedule of a 96-landmark synthetic frame (tests/track_scene.py)"""
+    sys.path.insert(0, os.path.dirname(HERE))
+    import track_scene as ts
+    sc = ts.Scene(n=96, seed=3)
+    cam = orc.track_camera(ts.P_LEFT, ts.P_RIGHT, ts.K_INV, ts.W, ts.H)
+    rec, seg = orc.track_plan(cam, sc.T_est_w2l, sc.dp_T, sc.motion_scaling, sc.xyz_world, sc.kp_size, sc.last_disparity, sc.uv_reference,
+                              sc.dp_index)
+    s0, roi0 = orc.track_epipolar_samples(cam, rec, sc.kp_size, seg, 0)
+    s2, roi2 = orc.track_epipolar_samples(cam, rec, sc.kp_size, seg, 2)
+    om = orc.OracleFundamentalMatcher(cam, sc.stereo_dict())
+    out = {}
+    for name, res in (("s1", om.stage1(rec, sc.kp_size, sc.extract_one, sc.last_left, sc.last_right)),
+                      ("s2", om.stage2(rec, sc.kp_size, sc.detect_one, sc.extract_one, sc.last_left, sc.last_right)),
+                      ("s3", om.epipolar(rec, sc.kp_size, sc.extract_one, sc.last_left, sc.ref_desc))):
+        out[name + "_status"] = np.array([d["status"] for d in res], np.int32)
+        out[name + "_uv_left"] = np.array([d.get("uv_left", (0, 0)) for d in res], np.float32)
+        out[name + "_uv_right"] = np.array([d.get("uv_right", (0, 0)) for d in res], np.float32)
+        out[name + "_xyz"] = np.array([d.get("xyz", (0, 0, 0)) for d in res], np.float64)
+    np.savez_compressed(os.path.join(HERE, "track_small.npz"), records=rec.view(np.uint8).reshape(len(rec), -1), seg=seg, samples0=s0, roi0=roi0,
+                        samples2=s2, roi2=roi2, **out)
+
+
 def main():
+    track_golden()
     s = synth.make_descriptor_pair(257, 1023, seed=0xC2)
     gt = s["gate"]
     i, d = orc.match_hamming256(s["q"], s["t"], gt, s["cutoff"])

@@ -46,7 +46,10 @@ def test_struct_layouts_match_header():
     probe = r'''
 #include <stdio.h>
 #include "svi_hot.h"
-int main(void){ printf("%zu %zu %zu %d\n", sizeof(svi_gate), sizeof(svi_ba_options), sizeof(svi_ba_stats), (int)SVI_PH_COUNT); return 0; }
+#include <stddef.h>
+int main(void){ printf("%zu %zu %zu %d %zu %zu %zu %zu %zu\n", sizeof(svi_gate), sizeof(svi_ba_options), sizeof(svi_ba_stats), (int)SVI_PH_COUNT,
+  sizeof(svi_track_camera), sizeof(svi_track_stereo_params), sizeof(svi_track_record), offsetof(svi_track_record, uv_left),
+  offsetof(svi_track_record, s3_count)); return 0; }
 '''
     with tempfile.TemporaryDirectory() as d:
         c = os.path.join(d, "p.c")
@@ -58,6 +61,13 @@ int main(void){ printf("%zu %zu %zu %d\n", sizeof(svi_gate), sizeof(svi_ba_optio
     assert int(out[1]) == C.sizeof(_capi.BaOptions)
     assert int(out[2]) == C.sizeof(_capi.BaStats)
     assert int(out[3]) == len(_capi.SVI_PH_NAMES)
+    assert int(out[4]) == C.sizeof(_capi.TrackCamera)
+    assert int(out[5]) == C.sizeof(_capi.TrackStereoParams)
+    import numpy as np
+    rec = np.dtype(_capi.TRACK_RECORD_FIELDS)
+    assert int(out[6]) == rec.itemsize == _capi.TRACK_RECORD_SIZE
+    assert int(out[7]) == rec.fields["uv_left"][1]
+    assert int(out[8]) == rec.fields["s3_count"][1]
 
 
 def test_no_silent_cpu_fallback(svi):
