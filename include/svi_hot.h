@@ -100,6 +100,15 @@ int svi_match_hamming256_dev(svi_matcher* m, const uint8_t* q, int nq, const uin
                              int batch, const svi_gate* gate, int max_dist_exclusive,
                              int32_t* out_idx, int32_t* out_dist);
 
+/* Loop-closure candidate search, the USING_BF variant: the query key frame's descriptor pool
+ * against the pool of EVERY past key frame, k = 1 per (key frame, query), kept iff MAXIMUM_DISTANCE_HAMMING (25,
+ * CKeyFrame.h:12) > distance  (CTrackerSVI.cpp:1221-1259, CTrackerSV.cpp:725-763, CTrackerGT.cpp:425-452).
+ *   pools: the key frames' pools back to back (32 B rows), pool_seg: n_clouds+1 row offsets (device), max_pool:
+ *   the largest pool (host; only sizes the launch);  out_idx / out_dist: n_clouds x nq, row c = key frame c,
+ *   out_idx = row INSIDE that key frame's pool (cv::DMatch::trainIdx) or -1, out_dist as svi_match_hamming256. */
+int svi_match_clouds_dev(svi_matcher* m, const uint8_t* q, int nq, const uint8_t* pools, const int32_t* pool_seg,
+                         int n_clouds, int max_pool, int max_dist_exclusive, int32_t* out_idx, int32_t* out_dist);
+
 /* dist[i] = popcount(a_i ^ b_i), i < n  (cv::norm(a,b,NORM_HAMMING) batched). */
 int svi_hamming256_pairs(svi_matcher* m, const uint8_t* a, const uint8_t* b, int n, int32_t* dist);
 int svi_hamming256_pairs_dev(svi_matcher* m, const uint8_t* a, const uint8_t* b, int n, int32_t* dist);
@@ -395,6 +404,14 @@ int svi_ba_get_landmarks(svi_ba* ba, int64_t* ids, double* p /*n x 3*/);
  * |p|^2 >= sane_position_l2 together with its edges; *removed (nullable) = how many. The graph
  * must be re-initialised afterwards. */
 int svi_ba_prune_diverged(svi_ba* ba, int64_t* removed);
+/* The whole write-back of Cg2oOptimizer::optimize (:1468-1540) in one call, vertices in ascending-id order:
+ *   landmark: kept[k] = 1 and xyz[k] = estimate - shift when |estimate|^2 < sane_position_l2 (:1486-1489), else
+ *             kept[k] = 0, xyz[k] = 0 and the vertex leaves the graph with its edges (:1493-1503);
+ *   key frame: T[k] = estimate with translation - shift (:1527-1528).
+ * Array sizes are those of svi_ba_num_landmarks / svi_ba_num_poses BEFORE the call; any output may be NULL;
+ * shift NULL = 0; *erased (nullable) = landmarks removed (the graph must then be re-initialised). */
+int svi_ba_apply_optimization(svi_ba* ba, const double shift[3], int64_t* lm_ids, double* lm_xyz, uint8_t* lm_kept,
+                              int64_t* kf_ids, double* kf_T, int64_t* erased);
 
 /* --- .g2o text interchange (Cg2oOptimizer.cpp:495-497, 514) ------------------------------- */
 int svi_ba_load_g2o(svi_ba* ba, const char* path);

@@ -94,6 +94,7 @@ SIGNATURES = {
     "svi_matcher_stream": (vp, [vp]),
     "svi_match_hamming256": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.POINTER(Gate), C.c_int, vp, vp]),
     "svi_match_hamming256_dev": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.POINTER(Gate), C.c_int, vp, vp]),
+    "svi_match_clouds_dev": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
     "svi_hamming256_pairs": (C.c_int, [vp, vp, vp, C.c_int, vp]),
     "svi_hamming256_pairs_dev": (C.c_int, [vp, vp, vp, C.c_int, vp]),
     "svi_triangulate_rectified": (C.c_int, [vp] + [C.c_double] * 5 + [vp, vp, C.c_int, vp, vp]),
@@ -136,6 +137,7 @@ SIGNATURES = {
     "svi_ba_get_poses": (C.c_int, [vp, i64p, f64p]),
     "svi_ba_get_landmarks": (C.c_int, [vp, i64p, f64p]),
     "svi_ba_prune_diverged": (C.c_int, [vp, i64p]),
+    "svi_ba_apply_optimization": (C.c_int, [vp, f64p, i64p, f64p, u8p, i64p, f64p, i64p]),
     "svi_ba_load_g2o": (C.c_int, [vp, C.c_char_p]),
     "svi_ba_save_g2o": (C.c_int, [vp, C.c_char_p]),
     "svi_ba_set_allreduce": (C.c_int, [vp, ALLREDUCE_FN, vp]),

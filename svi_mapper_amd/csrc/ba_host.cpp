@@ -1118,6 +1118,36 @@ int svi_ba_prune_diverged(svi_ba* ba, int64_t* removed)
     return SVI_OK;
 }
 
+// _applyOptimizationToLandmarks + _applyOptimizationToKeyFrames (Cg2oOptimizer.cpp:1468-1540)
+int svi_ba_apply_optimization(svi_ba* ba, const double shift[3], int64_t* lm_ids, double* lm_xyz, uint8_t* lm_kept, int64_t* kf_ids,
+                              double* kf_T, int64_t* erased)
+{
+    if (!ba) return fail(SVI_ERR_INVALID, "null handle");
+    const double s[3] = {shift ? shift[0] : 0.0, shift ? shift[1] : 0.0, shift ? shift[2] : 0.0};
+    std::vector<int> ord(ba->lms.size());
+    std::iota(ord.begin(), ord.end(), 0);
+    std::sort(ord.begin(), ord.end(), [&](int a, int b) { return ba->lms[a].id < ba->lms[b].id; });
+    for (size_t k = 0; k < ord.size(); ++k) {
+        const HLm& l = ba->lms[ord[k]];
+        const bool sane = ba->opt.sane_position_l2 > l.p[0] * l.p[0] + l.p[1] * l.p[1] + l.p[2] * l.p[2];
+        if (lm_ids) lm_ids[k] = l.id;
+        if (lm_kept) lm_kept[k] = sane ? 1 : 0;
+        if (lm_xyz) for (int c = 0; c < 3; ++c) lm_xyz[3 * k + c] = sane ? l.p[c] - s[c] : 0.0;
+    }
+    std::vector<int> po(ba->poses.size());
+    std::iota(po.begin(), po.end(), 0);
+    std::sort(po.begin(), po.end(), [&](int a, int b) { return ba->poses[a].id < ba->poses[b].id; });
+    for (size_t k = 0; k < po.size(); ++k) {
+        const HPose& q = ba->poses[po[k]];
+        if (kf_ids) kf_ids[k] = q.id;
+        if (kf_T) {
+            memcpy(kf_T + 12 * k, q.T, 9 * sizeof(double));
+            for (int c = 0; c < 3; ++c) kf_T[12 * k + 9 + c] = q.T[9 + c] - s[c];
+        }
+    }
+    return svi_ba_prune_diverged(ba, erased);
+}
+
 int svi_ba_set_allreduce(svi_ba* ba, svi_allreduce_fn fn, void* user)
 {
     if (!ba) return fail(SVI_ERR_INVALID, "null handle");

@@ -39,6 +39,7 @@ struct MatchArgs {
     const float*  q_umax; // [batch][nq]
     float         v_tol;
     int           nq, nt;
+    const int32_t* t_seg; // cloud mode (null otherwise): pool z is rows [t_seg[z], t_seg[z+1]) of t, the queries are shared
     int           tiles_per_split; // pool tiles scanned by one block
     int           cutoff;          // keep iff cutoff > distance
     unsigned long long* keys;      // [batch][nq] when the pool is split over blocks, else null
@@ -115,11 +116,14 @@ __global__ __launch_bounds__(WAVES * 64) void k_match_hamming256(MatchArgs a)
     const int tid  = threadIdx.x;
     const int lane = tid & (kLanes - 1);
     const int wave = tid >> 6;
-    const size_t qbase = static_cast<size_t>(blockIdx.z) * a.nq;
-    const size_t tbase = static_cast<size_t>(blockIdx.z) * a.nt;
+    const size_t obase = static_cast<size_t>(blockIdx.z) * a.nq;           // rows of the outputs
+    const size_t qbase = a.t_seg ? 0 : obase;                               // rows of the queries
+    const size_t tbase = a.t_seg ? static_cast<size_t>(a.t_seg[blockIdx.z]) : static_cast<size_t>(blockIdx.z) * a.nt;
+    const int    nt    = a.t_seg ? a.t_seg[blockIdx.z + 1] - a.t_seg[blockIdx.z] : a.nt;
     const int  qi     = blockIdx.x * kLanes + lane;
     const bool qvalid = qi < a.nq;
     const size_t qglob = qbase + (qvalid ? qi : 0);
+    const size_t oglob = obase + (qvalid ? qi : 0);
 
     uint4 q0 = make_uint4(0, 0, 0, 0), q1 = q0;
     float qu = 0.f, qv = 0.f, umin = 0.f, umax = 0.f;
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_match_hamming256(MatchArgs a)
 
     uint32_t best_d = 0xFFFFFFFFu, best_j = 0xFFFFFFFFu;
     const int tile0 = blockIdx.y * a.tiles_per_split;
-    const int ntile = (a.nt + TILE - 1) / TILE;
+    const int ntile = (nt + TILE - 1) / TILE;
     const int tile1 = min(tile0 + a.tiles_per_split, ntile);
 
     // register staging of the next tile (issue early, write to LDS late)
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_match_hamming256(MatchArgs a)
     float2 r_uv = make_float2(0.f, 0.f);
     auto fetch = [&](int tile) {
         const int j = tile * TILE + tid;
-        if (j < a.nt) {
+        if (j < nt) {
             r_lo = a.t[2 * (tbase + j)];
             r_hi = a.t[2 * (tbase + j) + 1];
             if (GATED) r_uv = a.t_uv[tbase + j];
@@ -160,7 +164,7 @@ __global__ __launch_bounds__(WAVES * 64) void k_match_hamming256(MatchArgs a)
         if (tile + 1 < tile1) fetch(tile + 1);
 
         const int jbase = tile * TILE + wave * kLanes;
-        const int jn    = min(kLanes, a.nt - jbase); // may be <= 0 for the ragged last tile
+        const int jn    = min(kLanes, nt - jbase); // may be <= 0 for the ragged last tile
 #pragma unroll 4
         for (int jj = 0; jj < jn; ++jj) {
             const int sj = wave * kLanes + jj;
@@ -188,9 +192,9 @@ __global__ __launch_bounds__(WAVES * 64) void k_match_hamming256(MatchArgs a)
 #pragma unroll
         for (int w = 1; w < WAVES; ++w) k = min(k, s_key[w][lane]);
         if (a.keys) {
-            if (k != kNoKey) atomicMin(&a.keys[qglob], k);
+            if (k != kNoKey) atomicMin(&a.keys[oglob], k);
         } else {
-            write_result(a, qglob, tbase, k, qu, qv);
+            write_result(a, oglob, tbase, k, qu, qv);
         }
     }
 }
@@ -204,7 +208,7 @@ __global__ __launch_bounds__(256) void k_match_finalize(MatchArgs a, int batch)
     const size_t b = i / a.nq;
     float qu = 0.f, qv = 0.f;
     if (a.out_xyz) { const float2 uv = a.q_uv[i]; qu = uv.x; qv = uv.y; }
-    write_result(a, i, b * a.nt, a.keys[i], qu, qv);
+    write_result(a, i, a.t_seg ? static_cast<size_t>(a.t_seg[b]) : b * a.nt, a.keys[i], qu, qv);
 }
 
 __global__ __launch_bounds__(256) void k_hamming256_pairs(const uint4* a, const uint4* b, int n, int32_t* dist)
@@ -275,7 +279,7 @@ void* svi_matcher_stream(svi_matcher* m) { return m ? static_cast<void*>(m->stre
 static int launch_match(svi_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, int batch,
                         const svi_gate* gate, int cutoff, int32_t* out_idx, int32_t* out_dist,
                         bool fuse, double f, double cx, double cy, double dur, double min_disp, double* out_xyz,
-                        uint8_t* out_ok)
+                        uint8_t* out_ok, const int32_t* t_seg = nullptr)
 {
     if (!m) return svi::fail(SVI_ERR_INVALID, "null matcher");
     if (nq < 0 || nt < 0 || batch < 0) return svi::fail(SVI_ERR_INVALID, "negative size");
@@ -296,7 +300,7 @@ static int launch_match(svi_matcher* m, const uint8_t* q, int nq, const uint8_t*
         a.t_uv = reinterpret_cast<const float2*>(gate->t_uv);
         a.q_umin = gate->q_umin; a.q_umax = gate->q_umax; a.v_tol = gate->v_tol;
     }
-    a.nq = nq; a.nt = nt; a.cutoff = cutoff;
+    a.nq = nq; a.nt = nt; a.cutoff = cutoff; a.t_seg = t_seg;
     a.out_idx = out_idx; a.out_dist = out_dist;
     if (fuse) { a.finv = 1.0 / f; a.cx = cx; a.cy = cy; a.dur = dur; a.min_disp = min_disp; a.out_xyz = out_xyz; a.out_ok = out_ok; }
 
@@ -343,6 +347,16 @@ int svi_match_hamming256_dev(svi_matcher* m, const uint8_t* q, int nq, const uin
                              const svi_gate* gate, int max_dist_exclusive, int32_t* out_idx, int32_t* out_dist)
 {
     return launch_match(m, q, nq, t, nt, batch, gate, max_dist_exclusive, out_idx, out_dist, false, 0, 0, 0, 0, 0, nullptr, nullptr);
+}
+
+int svi_match_clouds_dev(svi_matcher* m, const uint8_t* q, int nq, const uint8_t* pools, const int32_t* pool_seg, int n_clouds,
+                         int max_pool, int max_dist_exclusive, int32_t* out_idx, int32_t* out_dist)
+{
+    if (n_clouds > 0 && !pool_seg) return svi::fail(SVI_ERR_INVALID, "svi_match_clouds_dev: null pool_seg");
+    if (max_pool < 0) return svi::fail(SVI_ERR_INVALID, "svi_match_clouds_dev: max_pool < 0");
+    if (n_clouds > 65535) return svi::fail(SVI_ERR_INVALID, "svi_match_clouds_dev: more than 65535 clouds per call");
+    return launch_match(m, q, nq, pools, max_pool, n_clouds, nullptr, max_dist_exclusive, out_idx, out_dist, false, 0, 0, 0, 0, 0, nullptr,
+                        nullptr, pool_seg);
 }
 
 int svi_match_triangulate_dev(svi_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, int batch,

@@ -151,6 +151,12 @@ class HammingMatcher:
                                                   _ptr(out_idx), _ptr(out_dist), _ptr(out_xyz), _ptr(out_ok)),
               "svi_match_triangulate_dev")
 
+    def match_clouds_dev(self, q, nq, pools, pool_seg, n_clouds, max_pool, out_idx, out_dist, max_dist_exclusive=25):
+        """Loop-closure candidates (USING_BF, CTrackerSVI.cpp:1221-1259): query pool vs every past key frame's pool;
+        out_idx / out_dist are n_clouds x nq, kept iff MAXIMUM_DISTANCE_HAMMING (25) > distance."""
+        check(self._lib.svi_match_clouds_dev(self._h, _ptr(q), int(nq), _ptr(pools), _ptr(pool_seg), int(n_clouds), int(max_pool),
+                                             int(max_dist_exclusive), _ptr(out_idx), _ptr(out_dist)), "svi_match_clouds_dev")
+
     def pairs_dev(self, a, b, n, out):
         check(self._lib.svi_hamming256_pairs_dev(self._h, _ptr(a), _ptr(b), int(n), _ptr(out)),
               "svi_hamming256_pairs_dev")

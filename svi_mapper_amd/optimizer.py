@@ -170,6 +170,20 @@ class BundleAdjuster:
         check(self._lib.svi_ba_prune_diverged(self._h, C.byref(n)), "svi_ba_prune_diverged")
         return n.value
 
+    def apply_optimization(self, shift=None):
+        """Cg2oOptimizer::_applyOptimizationToLandmarks / ToKeyFrames (Cg2oOptimizer.cpp:1468-1540):
+        returns dict(lm_ids, lm_xyz, lm_kept, kf_ids, kf_T, erased); diverged landmarks leave the graph."""
+        nl, npz = self.num_landmarks, self.num_poses
+        lm_ids, lm_xyz, kept = np.empty(nl, np.int64), np.empty((nl, 3)), np.empty(nl, np.uint8)
+        kf_ids, kf_T = np.empty(npz, np.int64), np.empty((npz, 12))
+        sh = None if shift is None else np.ascontiguousarray(shift, np.float64).reshape(3)
+        erased = C.c_int64(0)
+        check(self._lib.svi_ba_apply_optimization(self._h, sh.ctypes.data_as(_capi.f64p) if sh is not None else None,
+                                                  lm_ids.ctypes.data_as(_capi.i64p), lm_xyz.ctypes.data_as(_capi.f64p),
+                                                  kept.ctypes.data_as(_capi.u8p), kf_ids.ctypes.data_as(_capi.i64p),
+                                                  kf_T.ctypes.data_as(_capi.f64p), C.byref(erased)), "svi_ba_apply_optimization")
+        return dict(lm_ids=lm_ids, lm_xyz=lm_xyz, lm_kept=kept, kf_ids=kf_ids, kf_T=kf_T, erased=erased.value)
+
     # -- results -----------------------------------------------------------------------------------
     def _count(self, fn):
         n = C.c_int64(0)

@@ -172,6 +172,35 @@ def test_fixed_and_closure_edges(svi, oracle, small):
     np.testing.assert_array_equal(g.get_landmark(900001), o.get_landmark(900001))  # fixed stays put
 
 
+def test_write_back_rules(svi, oracle, small):
+    """_applyOptimizationToLandmarks / ToKeyFrames (Cg2oOptimizer.cpp:1468-1540): estimate - shift, diverged
+    landmarks (|p|^2 >= 1e12) leave the graph with their edges; checked against the oracle's graph after the same rule"""
+    g, _ = _make(svi.BundleAdjuster, small)
+    o, _ = _make(oracle.OracleBA, small)
+    for ba in (g, o):
+        ba.add_landmark(777777, [2e6, 1.0, 0.0])           # diverged, no edges
+        ba.initialize()
+        ba.optimize(2)
+    shift = np.array([10.0, -2.5, 0.125])
+    ids_o, p_o = o.get_landmarks()
+    idk_o, T_o = o.get_poses()
+    nl, ne = g.num_landmarks, g.num_edges
+    out = g.apply_optimization(shift)
+    assert out["erased"] == 1 and o.prune_diverged() == 1
+    assert g.num_landmarks == nl - 1 == o.num_landmarks and g.num_edges == ne == o.num_edges
+    assert np.array_equal(out["lm_ids"], ids_o) and np.array_equal(out["kf_ids"], idk_o)
+    gone = out["lm_ids"] == 777777
+    assert np.array_equal(out["lm_kept"], (~gone).astype(np.uint8)) and np.all(out["lm_xyz"][gone] == 0)
+    assert _rel(out["lm_xyz"][~gone], p_o[~gone] - shift) < REL
+    assert np.abs(out["kf_T"][:, :9] - T_o[:, :9]).max() < REL and _rel(out["kf_T"][:, 9:], T_o[:, 9:] - shift) < REL
+    # the write-back is an exact subtraction of what the getters report
+    ids_g, p_g = g.get_landmarks()
+    keep = ~gone
+    assert np.array_equal(ids_g, out["lm_ids"][keep]) and np.array_equal(p_g - shift, out["lm_xyz"][keep])
+    g.initialize()                                           # the pruned graph optimises on
+    assert g.optimize(1) == 1
+
+
 def test_unsupported_shapes_fail_loudly(svi, small):
     ba, _ = _make(svi.BundleAdjuster, small)
     ba.add_edge_lm_lm(3, 4, np.zeros(3), np.array([1, 0, 0, 1, 0, 1.0]))

@@ -141,6 +141,44 @@ def test_batched_device_and_fused(matcher, oracle):
         assert (ok[sl][~hit] == 0).all()
 
 
+@pytest.mark.parametrize("n_clouds,nq,max_pool", [(1, 50, 700), (37, 800, 1500), (300, 64, 90), (3, 100, 30000)])
+def test_loop_closure_clouds(matcher, oracle, n_clouds, nq, max_pool):
+    """USING_BF loop-closure search (CTrackerSVI.cpp:1221-1259): the query pool against every past key frame's pool,
+    cut-off MAXIMUM_DISTANCE_HAMMING = 25; ragged pools incl. an empty one, planted revisits and ties"""
+    import torch
+    rng = np.random.default_rng(n_clouds * 31 + nq)
+    sizes = rng.integers(1, max_pool + 1, n_clouds)
+    sizes[-1] = max_pool
+    if n_clouds > 2:
+        sizes[1] = 0
+    seg = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    q = _rand_desc(rng, nq)
+    pools = _rand_desc(rng, int(seg[-1]))
+    for c in range(n_clouds):          # a third of the key frames revisit some query landmarks
+        if sizes[c] >= 4 and c % 3 == 0:
+            for k in rng.integers(0, nq, 8):
+                row = seg[c] + rng.integers(0, sizes[c])
+                d = q[k].copy()
+                d[rng.integers(0, 32, rng.integers(0, 6))] ^= 1
+                pools[row] = d
+                pools[seg[c] + rng.integers(0, sizes[c])] = pools[row]      # duplicate: lowest row must win
+    dev = torch.device("cuda:0")
+    idx = torch.empty(n_clouds * nq, dtype=torch.int32, device=dev)
+    dist = torch.empty_like(idx)
+    torch.cuda.synchronize()
+    matcher.match_clouds_dev(torch.from_numpy(q).to(dev), nq, torch.from_numpy(pools).to(dev), torch.from_numpy(seg).to(dev), n_clouds,
+                             int(sizes.max()), idx, dist)
+    matcher.synchronize()
+    idx, dist = idx.cpu().numpy().reshape(n_clouds, nq), dist.cpu().numpy().reshape(n_clouds, nq)
+    hits = 0
+    for c in range(n_clouds):
+        ridx, rdist = oracle.match_hamming256(q, pools[seg[c]:seg[c + 1]], None, 25)
+        np.testing.assert_array_equal(idx[c], ridx)
+        np.testing.assert_array_equal(dist[c], rdist)
+        hits += (ridx >= 0).sum()
+    assert hits > 0 or n_clouds == 1
+
+
 def test_split_pool_path(matcher, oracle):
     """Few queries, large ungated pool: the pool is split over workgroups and merged by atomicMin."""
     rng = np.random.default_rng(21)
