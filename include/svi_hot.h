@@ -284,6 +284,50 @@ int svi_track_stereo_verify_dev(svi_matcher* m, const svi_track_stereo_params* p
                                 float* out_uv_other, double* out_xyz);
 
 /* ------------------------------------------------------------------------------------------
+ * Frame pose from the stage-1/2 matches — replaces CSolverStereoPosit::getTransformationWORLDtoLEFT
+ * (src/optimization/CSolverStereoPosit.cpp:8-170): iteratively re-weighted Gauss-Newton on the
+ * stereo reprojection error, the whole loop in ONE launch (no host round trip per iteration).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct svi_posit_params {
+    double P_left[12], P_right[12];     /* m_matProjectionLEFT / RIGHT, 3x4 row-major                        */
+    int    min_points;                  /* 25   CSolverStereoPosit.h:89: solved iff min_points < n            */
+    int    min_inliers;                 /* 15   :90                                                           */
+    int    max_iterations;              /* 1000 :91                                                           */
+    double max_error_inlier_l2;         /* 10   :92  squared pixel error above which a point is down-weighted */
+    double max_error_average_l2;        /* 9    :93                                                           */
+    double max_risk;                    /* 2    :94                                                           */
+    double convergence_delta;           /* 1e-5 :95                                                           */
+    double min_translation_l2;          /* 1e-3 :98                                                           */
+} svi_posit_params;
+
+enum {
+    SVI_POSIT_OK            = 0,
+    SVI_POSIT_FEW_POINTS    = 1, /* "insufficient number of points"            (:168) */
+    SVI_POSIT_NOT_CONVERGED = 2, /* "system did not converge"                  (:165) */
+    SVI_POSIT_INACCURATE    = 3, /* "insufficient accuracy"                    (:127-130) */
+    SVI_POSIT_HIGH_RISK     = 4  /* "inconsistent with prior (HIGH RISK...)"   (:148-151) */
+};
+
+typedef struct svi_posit_result {
+    double  T_world_to_left[12];  /* R row-major then t; the estimate the loop ended with (also on failure)  */
+    double  error_average;        /* dErrorTotalPixelsL2 / n                                                 */
+    double  risk;                 /* dOptimizationRISK                                                       */
+    int32_t status;               /* SVI_POSIT_*  (the reference throws CExceptionPoseOptimization for 1..4) */
+    int32_t iterations;
+    int32_t inliers;
+    int32_t n;                    /* measurements used (active ones)                                         */
+} svi_posit_result;
+
+void svi_posit_params_default(svi_posit_params* p);
+/* poses and t_imu are host arrays (12 / 3 doubles); xyz_world n x 3 f64 (CMatch::vecPointXYZWORLD), uv_left / uv_right
+ * n x 2 f32 (CMatch::ptUVLEFT / ptUVRIGHT) and active (u8, nullable: e.g. status == OK of the tracking stages) are
+ * device arrays; result is a host struct - the call synchronises the matcher's stream. */
+int svi_stereo_posit_dev(svi_matcher* m, const svi_posit_params* prm, const double* T_world_to_left_last,
+                         const double* t_imu, const double* T_world_to_left_estimate, const double* xyz_world,
+                         const float* uv_left, const float* uv_right, const uint8_t* active, int n,
+                         svi_posit_result* result);
+
+/* ------------------------------------------------------------------------------------------
  * Bundle adjustment — replaces the g2o::SparseOptimizer m_cOptimizerSparse of Cg2oOptimizer
  * (Cg2oOptimizer.h:80) together with its solver stack (Cg2oOptimizer.cpp:83-89).
  * Vertex ids follow the reference: landmark id = uID, pose id = uID + 1e6 (Cg2oOptimizer.h:83);

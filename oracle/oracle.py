@@ -106,6 +106,7 @@ def load(path=None):
     lib.orc_track_stereo_verify.argtypes = [vp, _u8p, _u8p, _u8p, _f32p, _f32p, C.c_int, _i32p, _u8p, _f32p, _i32p, _i32p, _i32p,
                                             _f32p, _f64p]
     lib.orc_track_handover.argtypes = [C.c_int, vp, _f32p, _i32p, C.c_int, _i32p, _f32p, _i32p, _f32p, _f32p, _f32p, _u8p]
+    lib.orc_stereo_posit.argtypes = [vp, _f64p, _f64p, _f64p, _f64p, _f32p, _f32p, _u8p, C.c_int, vp]
     if path.endswith("liboracle.so"):
         _LIB = lib
     return lib
@@ -654,3 +655,40 @@ class OracleFundamentalMatcher:
             except NoMatch as e:
                 out[i] = dict(status=e.code)
         return out
+
+
+# ------------------------------------------------------------------------------------------------
+# CSolverStereoPosit (oracle_posit.c)
+# ------------------------------------------------------------------------------------------------
+class _PositParams(C.Structure):
+    _fields_ = [("P_left", C.c_double * 12), ("P_right", C.c_double * 12), ("min_points", C.c_int), ("min_inliers", C.c_int),
+                ("max_iterations", C.c_int), ("max_error_inlier_l2", C.c_double), ("max_error_average_l2", C.c_double),
+                ("max_risk", C.c_double), ("convergence_delta", C.c_double), ("min_translation_l2", C.c_double)]
+
+
+class _PositResult(C.Structure):
+    _fields_ = [("T", C.c_double * 12), ("error_average", C.c_double), ("risk", C.c_double), ("status", C.c_int32),
+                ("iterations", C.c_int32), ("inliers", C.c_int32), ("n", C.c_int32)]
+
+
+def posit_params(P_left, P_right, **kw):
+    p = _PositParams()
+    p.P_left[:] = np.asarray(P_left, np.float64).ravel().tolist()
+    p.P_right[:] = np.asarray(P_right, np.float64).ravel().tolist()
+    p.min_points, p.min_inliers, p.max_iterations = 25, 15, 1000               # CSolverStereoPosit.h:89-91
+    p.max_error_inlier_l2, p.max_error_average_l2, p.max_risk = 10.0, 9.0, 2.0  # :92-94
+    p.convergence_delta, p.min_translation_l2 = 1e-5, 0.001                     # :95, :98
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def stereo_posit(prm, T_last, t_imu, T_estimate, xyz_world, uv_left, uv_right, active=None, lib=None):
+    lib = lib or load()
+    Tl, Te, ti = _a(T_last, np.float64, 12), _a(T_estimate, np.float64, 12), _a(t_imu, np.float64, 3)
+    x, ul, ur, ac = _a(xyz_world, np.float64, (-1, 3)), _a(uv_left, np.float32, (-1, 2)), _a(uv_right, np.float32, (-1, 2)), _a(active, np.uint8)
+    r = _PositResult()
+    lib.orc_stereo_posit(C.byref(prm), _p(Tl, _f64p), _p(ti, _f64p), _p(Te, _f64p), _p(x, _f64p), _p(ul, _f32p), _p(ur, _f32p), _p(ac, _u8p),
+                         len(x), C.byref(r))
+    return dict(T=np.array(r.T[:]), error_average=r.error_average, risk=r.risk, status=r.status, iterations=r.iterations,
+                inliers=r.inliers, n=r.n)

@@ -60,6 +60,17 @@ TRK_EPI_BAD_PROJ, TRK_EPI_ZERO_LENGTH, TRK_EPI_OK = 16, 32, 64
  MATCH_OTHER_MISMATCH, MATCH_SKIPPED) = range(9)
 
 
+class PositParams(C.Structure):
+    _fields_ = [("P_left", C.c_double * 12), ("P_right", C.c_double * 12), ("min_points", C.c_int), ("min_inliers", C.c_int),
+                ("max_iterations", C.c_int), ("max_error_inlier_l2", C.c_double), ("max_error_average_l2", C.c_double),
+                ("max_risk", C.c_double), ("convergence_delta", C.c_double), ("min_translation_l2", C.c_double)]
+
+
+class PositResult(C.Structure):
+    _fields_ = [("T_world_to_left", C.c_double * 12), ("error_average", C.c_double), ("risk", C.c_double), ("status", C.c_int32),
+                ("iterations", C.c_int32), ("inliers", C.c_int32), ("n", C.c_int32)]
+
+
 class BaOptions(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("baseline_m", C.c_double), ("cauchy_delta", C.c_double), ("lm_tau", C.c_double),
@@ -110,6 +121,8 @@ SIGNATURES = {
     "svi_match_ragged_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "svi_track_stereo_verify_dev": (C.c_int, [vp, C.POINTER(TrackStereoParams), vp, vp, vp, vp, vp, C.c_int, vp, vp, vp,
                                               vp, vp, vp, vp, vp]),
+    "svi_posit_params_default": (None, [C.POINTER(PositParams)]),
+    "svi_stereo_posit_dev": (C.c_int, [vp, C.POINTER(PositParams), f64p, f64p, f64p, vp, vp, vp, vp, C.c_int, C.POINTER(PositResult)]),
     "svi_ba_options_default": (None, [C.POINTER(BaOptions)]),
     "svi_ba_create": (C.c_int, [C.POINTER(BaOptions), C.POINTER(vp)]),
     "svi_ba_destroy": (C.c_int, [vp]),

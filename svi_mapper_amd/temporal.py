@@ -14,8 +14,8 @@ landmarks of a frame in one launch and the exceptions become per-landmark status
 BRIEF extraction / GFTT detection are OpenCV's and stay with the caller: `extractor(side, roi, seg, kp_uv)` is
 called with device tensors (roi n x 4 f32, seg n+1 i32, kp_uv total x 2 f32 in ROI coordinates) and returns
 (seg', kp_uv', desc') - the key points it kept (OpenCV drops those too close to the ROI border) and their
-32-byte descriptors.  All tensors are torch CUDA tensors; only data_ptr() crosses the boundary and nothing is
-computed with torch beyond boolean masks and index lists.
+32-byte descriptors.  All tensors are torch CUDA tensors; only data_ptr() crosses the boundary and torch itself is
+used for boolean masks, index lists / gathers and three exactly rounded float32 expressions (4s, 8s+1, kp + 4s).
 """
 import ctypes as C
 
@@ -23,6 +23,7 @@ import numpy as np
 import torch
 
 from . import _capi
+from ._capi import PositParams, PositResult
 from ._capi import (MATCH_OK, MATCH_SKIPPED, TRACK_RECORD_FIELDS, TRACK_RECORD_SIZE, TRK_EPI_NO_MOTION, TRK_EPI_OK, TRK_FOV_LEFT,
                     TRK_FOV_RIGHT, TrackCamera, TrackStereoParams, check)
 from .matcher import HammingMatcher
@@ -385,3 +386,48 @@ class FundamentalMatcher:
             todo = todo[~found]
             depth += self.recursion_step
         return res
+
+
+class PoseOptimizationError(Exception):
+    """CExceptionPoseOptimization (src/exceptions/CExceptionPoseOptimization.h)"""
+
+    def __init__(self, message, result):
+        super().__init__(message)
+        self.result = result
+
+
+class SolverStereoPosit:
+    """CSolverStereoPosit (src/optimization/CSolverStereoPosit.{h,cpp}): frame pose from the tracked measurements,
+    the whole re-weighted Gauss-Newton loop in one launch."""
+
+    _messages = {1: "insufficient number of points", 2: "system did not converge", 3: "insufficient accuracy",
+                 4: "inconsistent with prior (HIGH RISK)"}
+
+    def __init__(self, P_left, P_right, matcher=None, device=0):
+        self.matcher = matcher or HammingMatcher(device)
+        self._lib = _capi.load_library()
+        self.params = PositParams()
+        self._lib.svi_posit_params_default(C.byref(self.params))
+        self.params.P_left[:] = np.asarray(P_left, np.float64).ravel().tolist()
+        self.params.P_right[:] = np.asarray(P_right, np.float64).ravel().tolist()
+        self.device = torch.device("cuda", device)
+        self._ext = torch.cuda.ExternalStream(self.matcher.stream, device=self.device)
+
+    def solve(self, T_world_to_left_last, t_imu, T_world_to_left_estimate, xyz_world, uv_left, uv_right, active=None):
+        """-> PositResult (status 0) ; device tensors xyz_world n x 3 f64, uv_* n x 2 f32, active u8 or None"""
+        Tl = np.ascontiguousarray(T_world_to_left_last, np.float64).reshape(12)
+        Te = np.ascontiguousarray(T_world_to_left_estimate, np.float64).reshape(12)
+        ti = np.ascontiguousarray(t_imu, np.float64).reshape(3)
+        res = PositResult()
+        self._ext.wait_stream(torch.cuda.current_stream(self.device))
+        check(self._lib.svi_stereo_posit_dev(self.matcher._h, C.byref(self.params), Tl.ctypes.data_as(_capi.f64p), ti.ctypes.data_as(_capi.f64p),
+                                             Te.ctypes.data_as(_capi.f64p), _p(xyz_world), _p(uv_left), _p(uv_right), _p(active),
+                                             int(xyz_world.shape[0]), C.byref(res)), "svi_stereo_posit_dev")
+        return res
+
+    def get_transformation_world_to_left(self, T_last, t_imu, T_estimate, xyz_world, uv_left, uv_right, active=None):
+        """getTransformationWORLDtoLEFT: the refined 12-vector, or CExceptionPoseOptimization as the reference throws"""
+        r = self.solve(T_last, t_imu, T_estimate, xyz_world, uv_left, uv_right, active)
+        if r.status != 0:
+            raise PoseOptimizationError(self._messages.get(r.status, "failed"), r)
+        return np.array(r.T_world_to_left[:])

@@ -1,0 +1,114 @@
+"""GPU parity of the frame-pose solver (svi_mapper_amd/csrc/posit.hip) against oracle/oracle_posit.c.
+Floating point: the GPU sums the measurements in a fixed tree instead of one after the other, so the tolerance is
+1e-9 absolute on the pose (metres / rotation entries), 1e-9 relative on the error sums, identical iteration counts,
+statuses and inlier counts.  PARITY UNPINNED with respect to the reference itself."""
+import numpy as np
+import pytest
+
+import posit_case
+import track_scene as ts
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def solver(svi, torch):
+    from svi_mapper_amd import temporal
+    return temporal.SolverStereoPosit(ts.P_LEFT, ts.P_RIGHT)
+
+
+def run_both(oracle, torch, solver, c, active=None, t_imu=None, **kw):
+    prm = oracle.posit_params(ts.P_LEFT, ts.P_RIGHT, **kw)
+    for k, v in kw.items():
+        setattr(solver.params, k, v)
+    t_imu = c["t_imu"] if t_imu is None else t_imu
+    want = oracle.stereo_posit(prm, c["T_last"], t_imu, c["T_est"], c["xyz"], c["uvl"], c["uvr"], active)
+    d = lambda a: None if a is None else torch.tensor(np.ascontiguousarray(a), device="cuda")  # noqa: E731
+    got = solver.solve(c["T_last"], t_imu, c["T_est"], d(c["xyz"]), d(c["uvl"]), d(c["uvr"]), d(active))
+    solver._lib.svi_posit_params_default  # noqa: B018
+    for k in kw:                                  # restore the defaults for the next test
+        setattr(solver.params, k, getattr(oracle.posit_params(ts.P_LEFT, ts.P_RIGHT), k))
+    return got, want
+
+
+def same(got, want):
+    assert got.status == want["status"] and got.n == want["n"]
+    assert got.iterations == want["iterations"] and got.inliers == want["inliers"]
+    assert np.abs(np.array(got.T_world_to_left[:]) - want["T"]).max() < 1e-9
+    assert abs(got.error_average - want["error_average"]) <= 1e-9 * max(1.0, abs(want["error_average"]))
+    assert abs(got.risk - want["risk"]) <= 1e-9 * max(1.0, abs(want["risk"]))
+
+
+@pytest.mark.parametrize("n,seed,noise,outliers", [(26, 1, 0.3, 0.0), (300, 2, 0.3, 0.1), (1000, 3, 0.5, 0.2), (5000, 4, 0.2, 0.05),
+                                                   (257, 5, 0.0, 0.0)])
+def test_pose_matches_oracle(oracle, torch, solver, n, seed, noise, outliers):
+    c = posit_case.make(n, seed, noise, outliers)
+    got, want = run_both(oracle, torch, solver, c)
+    assert want["status"] == 0
+    same(got, want)
+    assert np.abs(np.array(got.T_world_to_left[:]) - c["T_true"]).max() < 5e-3
+
+
+def test_failure_branches_and_mask(oracle, torch, solver):
+    c = posit_case.make(25, 3)
+    got, want = run_both(oracle, torch, solver, c)
+    assert want["status"] == 1
+    same(got, want)
+    c = posit_case.make(400, 8)
+    active = (np.random.default_rng(1).random(400) < 0.7).astype(np.uint8)
+    got, want = run_both(oracle, torch, solver, c, active)
+    assert want["status"] == 0 and want["n"] == active.sum()
+    same(got, want)
+    active[:] = 0
+    active[:20] = 1
+    got, want = run_both(oracle, torch, solver, c, active)
+    assert want["status"] == 1
+    same(got, want)
+    got, want = run_both(oracle, torch, solver, c, max_iterations=2)
+    assert want["status"] == 2
+    same(got, want)
+    got, want = run_both(oracle, torch, solver, c, t_imu=np.array([3.0, 0.0, 0.0]))
+    assert want["status"] == 4
+    same(got, want)
+    s = posit_case.make(300, 6, motion=(0.001, 0.0, 0.0, 0.005, 0.0, 0.01))
+    got, want = run_both(oracle, torch, solver, s)
+    assert want["status"] == 0 and np.array_equal(np.array(got.T_world_to_left[9:12]), s["T_last"][9:])
+    same(got, want)
+    from svi_mapper_amd import temporal
+    with pytest.raises(temporal.PoseOptimizationError):
+        d = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda")  # noqa: E731
+        c = posit_case.make(10, 1)
+        solver.get_transformation_world_to_left(c["T_last"], c["t_imu"], c["T_est"], d(c["xyz"]), d(c["uvl"]), d(c["uvr"]))
+    lib = solver._lib
+    assert lib.svi_stereo_posit_dev(None, None, None, None, None, None, None, None, None, 0, None) == 1
+
+
+def test_fed_by_the_tracking_stages(oracle, torch, solver, svi):
+    """stage-1/2 StageResult -> pose: the masks and measurements stay on the device"""
+    from svi_mapper_amd import temporal
+    sc = ts.Scene(n=600, seed=7)
+    fm = temporal.FundamentalMatcher(temporal.StereoCamera(ts.P_LEFT, ts.P_RIGHT, ts.W, ts.H), matcher=solver.matcher)
+    d = lambda a: torch.tensor(np.ascontiguousarray(a), device="cuda")  # noqa: E731
+    plan = fm.plan(sc.T_est_w2l, sc.dp_T, sc.motion_scaling, d(sc.xyz_world), d(sc.kp_size), d(sc.last_disparity), d(sc.uv_reference), d(sc.dp_index))
+    res = fm.track_stage2(plan, sc.make_detector(torch, "cuda"), sc.make_extractor(torch, "cuda"), d(sc.last_left), d(sc.last_right))
+    active = res.ok().to(torch.uint8)
+    assert int(active.sum()) > 100
+    xyz = d(sc.xyz_world)
+    got = solver.solve(sc.T_est_w2l, np.zeros(3), sc.T_est_w2l, xyz, res.uv_left, res.uv_right, active)
+    prm = oracle.posit_params(ts.P_LEFT, ts.P_RIGHT)
+    want = oracle.stereo_posit(prm, sc.T_est_w2l, np.zeros(3), sc.T_est_w2l, sc.xyz_world, res.uv_left.cpu().numpy(), res.uv_right.cpu().numpy(),
+                               active.cpu().numpy())
+    same(got, want)
+    assert got.status == 0
+    # the refined rotation is closer to the true one than the (deliberately wrong) estimate was (the translation moved by less
+    # than m_dMinimumTranslationMetersL2 and is therefore reset to the last pose, CSolverStereoPosit.cpp:137-141)
+    err = lambda T: np.abs(np.asarray(T)[:9] - sc.T_true_w2l[:9]).max()  # noqa: E731
+    assert err(got.T_world_to_left[:]) < err(sc.T_est_w2l)
