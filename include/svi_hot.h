@@ -328,6 +328,39 @@ int svi_stereo_posit_dev(svi_matcher* m, const svi_posit_params* prm, const doub
                          svi_posit_result* result);
 
 /* ------------------------------------------------------------------------------------------
+ * Per-landmark refinement — replaces CLandmark::optimize / _getOptimizedLandmarkSTEREOUV (src/types/CLandmark.cpp:281-296,
+ * 447-581), run by the reference for every active landmark of every frame (CTrackerGT.cpp:197).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct svi_landmark_params {
+    int    min_measurements;      /* 5    CLandmark.h:98: refined iff min_measurements < count           */
+    int    cap_iterations;        /* 1000 :90                                                             */
+    double convergence_delta;     /* 1e-5 :93                                                             */
+    double kernel_max_error_l2;   /* 10   :95                                                             */
+    double min_inlier_ratio;      /* 0.5  :94                                                             */
+    double max_error_average_l2;  /* 9    :96                                                             */
+} svi_landmark_params;
+
+enum {
+    SVI_LM_OPT_SKIPPED       = 0, /* too few measurements: position kept, bIsOptimal = true  (:293-295)                  */
+    SVI_LM_OPT_OPTIMAL       = 1, /* converged, inlier ratio fine, average error below the limit: bIsOptimal = true     */
+    SVI_LM_OPT_CONVERGED     = 2, /* converged and accepted (uOptimizationsSuccessful++) but not optimal                */
+    SVI_LM_OPT_REJECTED      = 3, /* converged with too few inliers: initial guess kept, uOptimizationsFailed++ (:556)  */
+    SVI_LM_OPT_NOT_CONVERGED = 4  /* iteration cap reached: initial guess kept, uOptimizationsFailed++ (:573)           */
+};
+
+void svi_landmark_params_default(svi_landmark_params* p);
+/* All arrays on the device.  frame_P_left / frame_P_right: n_frames x 12 f64, the WORLD->image projection of every
+ * frame that holds a measurement (CMeasurementLandmark::matProjectionWORLDtoLEFT / RIGHT, Types.h:12-54);
+ * landmark l owns measurements [meas_seg[l], meas_seg[l+1]) in the order they were added: meas_frame (i32 index into
+ * the frame arrays), meas_uv_left / meas_uv_right (f32 pixels);  xyz_in / xyz_out n x 3 f64 (vecPointXYZOptimized);
+ * out_status SVI_LM_OPT_*, out_error_average = dCurrentAverageSquaredError, out_iterations.  Asynchronous. */
+int svi_landmarks_optimize_dev(svi_matcher* m, const svi_landmark_params* prm, const double* frame_P_left,
+                               const double* frame_P_right, int n_frames, const int32_t* meas_seg,
+                               const int32_t* meas_frame, const float* meas_uv_left, const float* meas_uv_right,
+                               const double* xyz_in, int n, double* xyz_out, int32_t* out_status,
+                               double* out_error_average, int32_t* out_iterations);
+
+/* ------------------------------------------------------------------------------------------
  * Bundle adjustment — replaces the g2o::SparseOptimizer m_cOptimizerSparse of Cg2oOptimizer
  * (Cg2oOptimizer.h:80) together with its solver stack (Cg2oOptimizer.cpp:83-89).
  * Vertex ids follow the reference: landmark id = uID, pose id = uID + 1e6 (Cg2oOptimizer.h:83);

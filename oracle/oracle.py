@@ -106,6 +106,7 @@ def load(path=None):
     lib.orc_track_stereo_verify.argtypes = [vp, _u8p, _u8p, _u8p, _f32p, _f32p, C.c_int, _i32p, _u8p, _f32p, _i32p, _i32p, _i32p,
                                             _f32p, _f64p]
     lib.orc_track_handover.argtypes = [C.c_int, vp, _f32p, _i32p, C.c_int, _i32p, _f32p, _i32p, _f32p, _f32p, _f32p, _u8p]
+    lib.orc_landmarks_optimize.argtypes = [vp, _f64p, _f64p, C.c_int, _i32p, _i32p, _f32p, _f32p, _f64p, C.c_int, _f64p, _i32p, _f64p, _i32p]
     lib.orc_stereo_posit.argtypes = [vp, _f64p, _f64p, _f64p, _f64p, _f32p, _f32p, _u8p, C.c_int, vp]
     if path.endswith("liboracle.so"):
         _LIB = lib
@@ -692,3 +693,30 @@ def stereo_posit(prm, T_last, t_imu, T_estimate, xyz_world, uv_left, uv_right, a
                          len(x), C.byref(r))
     return dict(T=np.array(r.T[:]), error_average=r.error_average, risk=r.risk, status=r.status, iterations=r.iterations,
                 inliers=r.inliers, n=r.n)
+
+
+# ------------------------------------------------------------------------------------------------
+# CLandmark::optimize (oracle_landmark.c)
+# ------------------------------------------------------------------------------------------------
+class _LandmarkParams(C.Structure):
+    _fields_ = [("min_measurements", C.c_int), ("cap_iterations", C.c_int), ("convergence_delta", C.c_double),
+                ("kernel_max_error_l2", C.c_double), ("min_inlier_ratio", C.c_double), ("max_error_average_l2", C.c_double)]
+
+
+def landmark_params(**kw):
+    p = _LandmarkParams(5, 1000, 1e-5, 10.0, 0.5, 9.0)     # CLandmark.h:90-98
+    for k, v in kw.items():
+        setattr(p, k, v)
+    return p
+
+
+def landmarks_optimize(prm, frame_P_left, frame_P_right, seg, meas_frame, uvl, uvr, xyz, lib=None):
+    lib = lib or load()
+    PL, PR = _a(frame_P_left, np.float64, (-1, 12)), _a(frame_P_right, np.float64, (-1, 12))
+    seg, fr = _a(seg, np.int32), _a(meas_frame, np.int32)
+    ul, ur, x = _a(uvl, np.float32, (-1, 2)), _a(uvr, np.float32, (-1, 2)), _a(xyz, np.float64, (-1, 3))
+    n = len(x)
+    out, st, err, its = np.zeros((n, 3)), np.zeros(n, np.int32), np.zeros(n), np.zeros(n, np.int32)
+    lib.orc_landmarks_optimize(C.byref(prm), _p(PL, _f64p), _p(PR, _f64p), len(PL), _p(seg, _i32p), _p(fr, _i32p), _p(ul, _f32p), _p(ur, _f32p),
+                               _p(x, _f64p), n, _p(out, _f64p), _p(st, _i32p), _p(err, _f64p), _p(its, _i32p))
+    return out, st, err, its

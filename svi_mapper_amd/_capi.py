@@ -71,6 +71,11 @@ class PositResult(C.Structure):
                 ("iterations", C.c_int32), ("inliers", C.c_int32), ("n", C.c_int32)]
 
 
+class LandmarkParams(C.Structure):
+    _fields_ = [("min_measurements", C.c_int), ("cap_iterations", C.c_int), ("convergence_delta", C.c_double),
+                ("kernel_max_error_l2", C.c_double), ("min_inlier_ratio", C.c_double), ("max_error_average_l2", C.c_double)]
+
+
 class BaOptions(C.Structure):
     _fields_ = [("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double),
                 ("baseline_m", C.c_double), ("cauchy_delta", C.c_double), ("lm_tau", C.c_double),
@@ -123,6 +128,8 @@ SIGNATURES = {
                                               vp, vp, vp, vp, vp]),
     "svi_posit_params_default": (None, [C.POINTER(PositParams)]),
     "svi_stereo_posit_dev": (C.c_int, [vp, C.POINTER(PositParams), f64p, f64p, f64p, vp, vp, vp, vp, C.c_int, C.POINTER(PositResult)]),
+    "svi_landmark_params_default": (None, [C.POINTER(LandmarkParams)]),
+    "svi_landmarks_optimize_dev": (C.c_int, [vp, C.POINTER(LandmarkParams), vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]),
     "svi_ba_options_default": (None, [C.POINTER(BaOptions)]),
     "svi_ba_create": (C.c_int, [C.POINTER(BaOptions), C.POINTER(vp)]),
     "svi_ba_destroy": (C.c_int, [vp]),

@@ -23,7 +23,7 @@ import numpy as np
 import torch
 
 from . import _capi
-from ._capi import PositParams, PositResult
+from ._capi import LandmarkParams, PositParams, PositResult
 from ._capi import (MATCH_OK, MATCH_SKIPPED, TRACK_RECORD_FIELDS, TRACK_RECORD_SIZE, TRK_EPI_NO_MOTION, TRK_EPI_OK, TRK_FOV_LEFT,
                     TRK_FOV_RIGHT, TrackCamera, TrackStereoParams, check)
 from .matcher import HammingMatcher
@@ -431,3 +431,31 @@ class SolverStereoPosit:
         if r.status != 0:
             raise PoseOptimizationError(self._messages.get(r.status, "failed"), r)
         return np.array(r.T_world_to_left[:])
+
+
+class LandmarkOptimizer:
+    """CLandmark::optimize for all active landmarks of a frame (src/types/CLandmark.cpp:281-296, 447-581)."""
+
+    SKIPPED, OPTIMAL, CONVERGED, REJECTED, NOT_CONVERGED = range(5)
+
+    def __init__(self, matcher=None, device=0):
+        self.matcher = matcher or HammingMatcher(device)
+        self._lib = _capi.load_library()
+        self.params = LandmarkParams()
+        self._lib.svi_landmark_params_default(C.byref(self.params))
+        self.device = torch.device("cuda", device)
+        self._ext = torch.cuda.ExternalStream(self.matcher.stream, device=self.device)
+
+    def optimize(self, frame_P_left, frame_P_right, meas_seg, meas_frame, meas_uv_left, meas_uv_right, xyz):
+        """-> (xyz_optimized, status, error_average, iterations); bIsOptimal = status in (SKIPPED, OPTIMAL)"""
+        n = xyz.shape[0]
+        out = torch.empty_like(xyz)
+        status = torch.empty((n,), dtype=torch.int32, device=self.device)
+        err = torch.empty((n,), dtype=torch.float64, device=self.device)
+        its = torch.empty((n,), dtype=torch.int32, device=self.device)
+        self._ext.wait_stream(torch.cuda.current_stream(self.device))
+        check(self._lib.svi_landmarks_optimize_dev(self.matcher._h, C.byref(self.params), _p(frame_P_left), _p(frame_P_right),
+                                                   int(frame_P_left.shape[0]), _p(meas_seg), _p(meas_frame), _p(meas_uv_left), _p(meas_uv_right),
+                                                   _p(xyz), n, _p(out), _p(status), _p(err), _p(its)), "svi_landmarks_optimize_dev")
+        torch.cuda.current_stream(self.device).wait_stream(self._ext)
+        return out, status, err, its
