@@ -118,6 +118,71 @@ def bench_matcher(svi, steps=1000, warmup=50):
             "value": out["gated_single"]["pairs_per_s"], "unit": "pairs/s", "dtype": "u8", **out}
 
 
+def bench_frontend(svi, reps=200):
+    """Secondary: the per-frame passes around the matcher on frame-sized synthetic inputs.
+    Launch/latency bound by nature (a few thousand landmarks); reported as ms per call with the stream drained."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import landmark_case
+    import posit_case
+    import track_scene as ts
+    from svi_mapper_amd import temporal
+    dev = torch.device("cuda", torch.cuda.current_device())
+    d = lambda a: torch.tensor(np.ascontiguousarray(a), device=dev)  # noqa: E731
+    out = {}
+
+    def timed(fn, n=reps):
+        for _ in range(5):
+            fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        return 1e3 * (time.perf_counter() - t0) / n
+
+    sc = ts.Scene(n=2000, seed=7)
+    fm = temporal.FundamentalMatcher(temporal.StereoCamera(ts.P_LEFT, ts.P_RIGHT, ts.W, ts.H), device=dev.index)
+    args = (sc.T_est_w2l, sc.dp_T, sc.motion_scaling, d(sc.xyz_world), d(sc.kp_size), d(sc.last_disparity), d(sc.uv_reference), d(sc.dp_index))
+    plan = fm.plan(*args)
+    out["track_plan_2000_landmarks_ms"] = timed(lambda: fm.plan(*args))
+    out["epipolar_samples_ms"] = timed(lambda: fm.epipolar_samples(plan, 0))
+    seg = plan.seg
+    rng = np.random.default_rng(0)
+    pool = d(rng.integers(0, 256, (plan.total, 32), dtype=np.uint8))
+    ll, rf = d(sc.last_left), d(sc.ref_desc)
+    out["ragged_match_ms"] = timed(lambda: fm.get_match(ll, rf, seg, pool, 50, 100))
+    out["ragged_match_candidates"] = int(plan.total)
+    # loop closure: 2000 query descriptors against 200 key frames x ~1500 descriptors
+    nq, n_clouds = 2000, 200
+    sizes = rng.integers(1000, 2000, n_clouds)
+    cseg = np.concatenate([[0], np.cumsum(sizes)]).astype(np.int32)
+    pools = d(rng.integers(0, 256, (int(cseg[-1]), 32), dtype=np.uint8))
+    q = d(rng.integers(0, 256, (nq, 32), dtype=np.uint8))
+    idx = torch.empty(n_clouds * nq, dtype=torch.int32, device=dev)
+    dist = torch.empty_like(idx)
+    cs = d(cseg)
+
+    def clouds():
+        fm.matcher.match_clouds_dev(q, nq, pools, cs, n_clouds, int(sizes.max()), idx, dist)
+        fm.matcher.synchronize()
+    ms = timed(clouds, 50)
+    out["loop_closure_200_keyframes_ms"] = ms
+    out["loop_closure_pairs_per_s"] = float(nq) * float(cseg[-1]) / (ms * 1e-3)
+    c = posit_case.make(500, 2)
+    solver = temporal.SolverStereoPosit(ts.P_LEFT, ts.P_RIGHT, matcher=fm.matcher, device=dev.index)
+    px, pl, pr = d(c["xyz"]), d(c["uvl"]), d(c["uvr"])
+    r = solver.solve(c["T_last"], c["t_imu"], c["T_est"], px, pl, pr)
+    out["stereo_posit_500_points_ms"] = timed(lambda: solver.solve(c["T_last"], c["t_imu"], c["T_est"], px, pl, pr))
+    out["stereo_posit_iterations"] = int(r.iterations)
+    lc = landmark_case.make(5000, 5)
+    lo = temporal.LandmarkOptimizer(matcher=fm.matcher, device=dev.index)
+    la = [d(lc[k]) for k in ("PL", "PR", "seg", "frame", "uvl", "uvr", "xyz0")]
+    out["landmark_optimize_5000_landmarks_ms"] = timed(lambda: lo.optimize(*la), 50)
+    out["landmark_measurements"] = int(lc["seg"][-1])
+    return out
+
+
 def cpu_baseline(prob, iters):
     """The CPU oracle (restatement of the g2o/CHOLMOD path), 1 thread, -O3 -march=native, timed on this host."""
     from oracle import oracle as orc
@@ -157,7 +222,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matcher", action="store_true")
-    ap.add_argument("--cpu-iters", type=int, default=10)
+    ap.add_argument("--no-frontend", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=30)
     ap.add_argument("--chol-tile", type=int, default=96)
     ap.add_argument("--backend", default="nccl")
     args = ap.parse_args()
@@ -254,6 +320,8 @@ def main():
     line["roofline_cholesky"]["frac"] = line["roofline_cholesky"]["achieved"] / FP64_MFMA_PEAK_TF
     if world == 1 and not args.no_matcher:
         line["matcher"] = bench_matcher(svi)
+    if world == 1 and not args.no_frontend:
+        line["frontend"] = bench_frontend(svi)
     if world == 1 and not args.no_cpu_baseline:
         line["cpu_baseline"] = cpu_baseline(prob, args.cpu_iters)
         line["speedup_vs_cpu_baseline"] = line["value"] / line["cpu_baseline"]["value"]
