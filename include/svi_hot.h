@@ -399,6 +399,9 @@ typedef struct svi_ba_options {
     int    profile;
     /* reduced camera system tile edge (multiple of 48; 0 = default 96) */
     int    chol_tile;
+    /* elimination order of the reduced camera system: 0 = nested dissection of the key-frame sequence (independent
+     * chains factorised side by side), 1 = natural (ascending id: one chain) */
+    int    chol_order;
 } svi_ba_options;
 
 void svi_ba_options_default(svi_ba_options* o);
@@ -525,6 +528,7 @@ typedef struct svi_ba_stats {
     int64_t n_edges_proj, n_edges_proj_local, n_edges_se3, n_edges_accel, n_edges_lmlm;
     int64_t n_schur_tiles, n_window_blocks;    /* K4 decomposition */
     int64_t chol_n, chol_tile, chol_tiles_nnz; /* reduced system */
+    int64_t chol_steps;                        /* dependency levels of its tile columns = launches on the critical path */
     int64_t reduce_doubles;                    /* payload of one all-reduce */
     double  chol_flops;                        /* of one factorisation on the tile structure */
     uint64_t lm_iterations, lm_trials, chol_failures;

@@ -84,14 +84,14 @@ class BaOptions(C.Structure):
                 ("max_depth_xyz_l2", C.c_double), ("max_depth_uvdepth_l2", C.c_double),
                 ("max_depth_uvdisp_l2", C.c_double), ("sane_position_l2", C.c_double),
                 ("device", C.c_int), ("stream", vp), ("rank", C.c_int), ("n_ranks", C.c_int),
-                ("profile", C.c_int), ("chol_tile", C.c_int)]
+                ("profile", C.c_int), ("chol_tile", C.c_int), ("chol_order", C.c_int)]
 
 
 class BaStats(C.Structure):
     _fields_ = [(n, C.c_int64) for n in
                 ("n_poses", "n_poses_free", "n_landmarks", "n_landmarks_local", "n_edges_proj",
                  "n_edges_proj_local", "n_edges_se3", "n_edges_accel", "n_edges_lmlm", "n_schur_tiles",
-                 "n_window_blocks", "chol_n", "chol_tile", "chol_tiles_nnz", "reduce_doubles")] + \
+                 "n_window_blocks", "chol_n", "chol_tile", "chol_tiles_nnz", "chol_steps", "reduce_doubles")] + \
                [("chol_flops", C.c_double), ("lm_iterations", C.c_uint64), ("lm_trials", C.c_uint64),
                 ("chol_failures", C.c_uint64)]
 

@@ -129,27 +129,29 @@ struct BaDev {
 
 // tile-sparse Cholesky of the reduced system (ba_chol.hip)
 struct CholPlan {
-    int TS = 0, NT = 0;
-    // per tile column k: sub-diagonal tiles and update triples, flattened
-    const int* col_ptr = nullptr;   // [NT+1] into trsm_tile
-    const int* trsm_tile = nullptr; // tile ids (i,k), i>k
-    const int* trsm_row = nullptr;  // tile row i
-    const int* upd_ptr = nullptr;   // [NT+1] into upd_*
-    const int* upd_a = nullptr;     // tile (i,k)
-    const int* upd_b = nullptr;     // tile (j,k)
-    const int* upd_c = nullptr;     // tile (i,j)
-    const int* upd_row = nullptr;   // tile row i of the target (g_i rides along on diagonal targets)
-    // host copies of the counts
-    const int* h_col_ptr = nullptr;
-    const int* h_upd_ptr = nullptr;
-    const int* h_diag_tile = nullptr; // tile id of (k,k)
-    const int* h_pre_tile = nullptr;  // tile id of (k,k-1) whose update of (k,k) is applied by the factorising workgroup, or -1
-    const int* diag_tile = nullptr;   // device copy
-    // row lists for the triangular solves
-    const int* row_ptr = nullptr;     // [NT+1] tiles (k,j), j<k  (device)
-    const int* row_tile = nullptr;
-    const int* row_col = nullptr;
-    const int* colb_ptr = nullptr;    // [NT+1] tiles (i,k), i>k  (device)  == col_ptr/trsm_tile/trsm_row
+    int TS = 0, NT = 0, n_steps = 0;
+    // host: ranges of one dependency level (= one launch) in the device lists
+    const int* h_step_ptr = nullptr;  // [n_steps+1] into step_col
+    const int* h_tgt_ptr = nullptr;   // [n_steps+1] into tgt_*: targets updated by the launch of step s
+    const int* h_trsm_ptr = nullptr;  // [n_steps+1] into st_tile / st_col
+    // device
+    const int* step_col = nullptr;    // tile columns of each level, ascending
+    const int* diag_tile = nullptr;   // [NT] tile id of (k,k)
+    const int* pre_ptr = nullptr;     // [NT+1]: updates of (k,k) applied by the workgroup that factorises it
+    const int* pre_tile = nullptr;    //   tile (k,q)
+    const int* pre_col = nullptr;     //   q  (y_q feeds the forward substitution)
+    const int* tgt_tile = nullptr;    // target tile of a grouped update
+    const int* tgt_row = nullptr;     //   its tile row if it is a diagonal tile (g rides along), else -1
+    const int* tgt_pair_ptr = nullptr;//   [n_targets+1] into pair_*
+    const int* pair_a = nullptr;      // tile (i,q)
+    const int* pair_b = nullptr;      // tile (j,q)
+    const int* pair_src = nullptr;    // q
+    const int* st_tile = nullptr;     // trsm items of a level: tile (i,k) ...
+    const int* st_col = nullptr;      // ... and its column k
+    const int* col_ptr = nullptr;     // [NT+1] sub-diagonal tiles of every column (back substitution)
+    const int* trsm_tile = nullptr;
+    const int* trsm_row = nullptr;
 };
+
 
 } // namespace svi

@@ -18,6 +18,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <functional>
 #include <numeric>
 
 #include "ba_math.h"
@@ -150,6 +151,50 @@ int build_structure(svi_ba* ba)
         else { pose_red[s] = (int)red_slot.size(); red_slot.push_back(s); }
     }
     const int Pf = (int)red_slot.size();
+    // ---- elimination order of the reduced camera system (nested dissection of the key-frame sequence) ----
+    // The reduced system of a trajectory is block-banded: in natural order its Cholesky is ONE chain of tile
+    // columns.  Cutting the sequence at separators as wide as the co-visibility span gives independent chains
+    // that are factorised side by side (ba_chol.hip processes all columns of one dependency level per launch).
+    // Every piece is a whole number of tiles except the top separator, which comes last and absorbs the
+    // remainder, so the identity padding stays at the end of the reduced index range.
+    ba->red_perm.resize(Pf);
+    std::iota(ba->red_perm.begin(), ba->red_perm.end(), 0);
+    {
+        int TSo = o.chol_tile > 0 ? o.chol_tile : 96;
+        const int PBo = TSo / 6;
+        int span = 0; // largest |r_i - r_j| over coupled free poses (natural reduced indices)
+        if (o.chol_order == 0 && PBo > 0 && Pf >= 6 * PBo) {
+            std::vector<int> lo(Ltot, INT32_MAX), hi(Ltot, -1);
+            for (const HProj& e : ba->proj) {
+                const int r = pose_red[pose_slot[e.pose]];
+                if (r >= 0 && !ba->lms[e.lm].fixed) { lo[e.lm] = std::min(lo[e.lm], r); hi[e.lm] = std::max(hi[e.lm], r); }
+            }
+            for (int l = 0; l < Ltot; ++l) if (hi[l] >= 0) span = std::max(span, hi[l] - lo[l]);
+            for (const HSe3& e : ba->se3) {
+                const int ri = pose_red[pose_slot[e.i]], rj = pose_red[pose_slot[e.j]];
+                if (ri >= 0 && rj >= 0) span = std::max(span, std::abs(ri - rj));
+            }
+        }
+        const int rem = Pf % PBo;
+        const int sep = ((std::max(span, 1) + PBo - 1) / PBo) * PBo;                                        // inner separators
+        const int sep_top = rem == 0 ? sep : rem + PBo * ((std::max(span - rem, 0) + PBo - 1) / PBo);     // absorbs the remainder
+        if (span > 0 && Pf >= sep_top + 4 * PBo) {
+            std::vector<std::pair<int, int>> pieces; // natural ranges in elimination order
+            std::function<void(int, int, int)> rec = [&](int a, int b, int w) {
+                const int len = b - a;
+                if (len < w + 2 * PBo) { if (len > 0) pieces.push_back({a, b}); return; }
+                const int left = PBo * (((len - w) / PBo) / 2);
+                rec(a, a + left, sep);
+                rec(a + left + w, b, sep);
+                pieces.push_back({a + left, a + left + w});
+            };
+            rec(0, Pf, sep_top);
+            int pos = 0;
+            for (auto& pc : pieces) for (int r = pc.first; r < pc.second; ++r) ba->red_perm[r] = pos++;
+            for (int sl = 0; sl < Pn; ++sl) if (pose_red[sl] >= 0) pose_red[sl] = ba->red_perm[pose_red[sl]];
+            for (int sl = 0; sl < Pn; ++sl) if (pose_red[sl] >= 0) red_slot[pose_red[sl]] = sl;
+        }
+    }
     ba->lm_order.resize(Ltot);
     std::iota(ba->lm_order.begin(), ba->lm_order.end(), 0);
     std::sort(ba->lm_order.begin(), ba->lm_order.end(), [&](int a, int b) { return ba->lms[a].id < ba->lms[b].id; });
@@ -348,48 +393,99 @@ int build_structure(svi_ba* ba)
         }
     }
     // symbolic fill, right-looking over tile columns
-    std::vector<int> h_col_ptr(NT + 1, 0), h_upd_ptr(NT + 1, 0);
+    std::vector<int> h_col_ptr(NT + 1, 0);
     std::vector<std::pair<int, int>> col_rows;            // (k, i)
     std::vector<int> upd_i, upd_j, upd_k;
     for (int k = 0; k < NT; ++k) {
         std::vector<int> rows;
         for (int i = k + 1; i < NT; ++i) if (nz[(size_t)i * NT + k]) rows.push_back(i);
         h_col_ptr[k] = (int)col_rows.size();
-        h_upd_ptr[k] = (int)upd_i.size();
         for (int i : rows) col_rows.push_back({k, i});
         for (size_t a = 0; a < rows.size(); ++a)
             for (size_t b = 0; b <= a; ++b) {
                 nz[(size_t)rows[a] * NT + rows[b]] = 1;
-                // the update of the next diagonal tile by its left neighbour is applied by the workgroup that
-                // factorises that tile (ba_chol.hip, fused step): not part of the update lists
-                if (rows[a] == k + 1 && rows[b] == k + 1) continue;
                 upd_i.push_back(rows[a]); upd_j.push_back(rows[b]); upd_k.push_back(k);
             }
     }
     h_col_ptr[NT] = (int)col_rows.size();
-    h_upd_ptr[NT] = (int)upd_i.size();
     std::vector<int> tile_map((size_t)NT * NT, -1), tile_ti, tile_tj;
     for (int j = 0; j < NT; ++j)
         for (int i = j; i < NT; ++i)
             if (nz[(size_t)i * NT + j]) { tile_map[(size_t)i * NT + j] = (int)tile_ti.size(); tile_ti.push_back(i); tile_tj.push_back(j); }
     const int n_tiles = (int)tile_ti.size();
-    std::vector<int> trsm_tile, trsm_row, upd_a, upd_b, upd_c, diag_tile(NT), pre_tile(NT, -1), row_ptr(NT + 1, 0), row_tile, row_col;
+    std::vector<int> trsm_tile, trsm_row, diag_tile(NT);
     for (auto& kr : col_rows) { trsm_tile.push_back(tile_map[(size_t)kr.second * NT + kr.first]); trsm_row.push_back(kr.second); }
-    for (size_t u = 0; u < upd_i.size(); ++u) {
-        upd_a.push_back(tile_map[(size_t)upd_i[u] * NT + upd_k[u]]);
-        upd_b.push_back(tile_map[(size_t)upd_j[u] * NT + upd_k[u]]);
-        upd_c.push_back(tile_map[(size_t)upd_i[u] * NT + upd_j[u]]);
+    for (int k = 0; k < NT; ++k) diag_tile[k] = tile_map[(size_t)k * NT + k];
+
+    // dependency levels: column c waits for every column p < c with a tile (c,p); all columns of one level are
+    // factorised by one launch (ba_chol.hip).  The update of a diagonal tile by a column of the level just below
+    // is applied by the workgroup that factorises it ("pre" list); every other update is grouped by TARGET tile
+    // and runs in the launch that follows its source column's level, one workgroup set per target with the
+    // sources in ascending order (no two workgroups ever write the same tile: deterministic without atomics).
+    std::vector<int> level(NT, 0);
+    for (int c = 0; c < NT; ++c)
+        for (int q = 0; q < c; ++q) if (tile_map[(size_t)c * NT + q] >= 0) level[c] = std::max(level[c], level[q] + 1);
+    const int n_steps = NT ? *std::max_element(level.begin(), level.end()) + 1 : 0;
+    std::vector<int> h_step_ptr(n_steps + 1, 0), step_col;
+    for (int st = 0; st < n_steps; ++st) {
+        h_step_ptr[st] = (int)step_col.size();
+        for (int c = 0; c < NT; ++c) if (level[c] == st) step_col.push_back(c);
     }
+    h_step_ptr[n_steps] = (int)step_col.size();
+    std::vector<int> pre_ptr(NT + 1, 0), pre_tile, pre_col;
+    for (int c = 0; c < NT; ++c) {
+        pre_ptr[c] = (int)pre_tile.size();
+        for (int q = 0; q < c; ++q)
+            if (tile_map[(size_t)c * NT + q] >= 0 && level[q] == level[c] - 1) { pre_tile.push_back(tile_map[(size_t)c * NT + q]); pre_col.push_back(q); }
+    }
+    pre_ptr[NT] = (int)pre_tile.size();
+    // target-grouped updates per launch step
+    std::vector<int> h_tgt_ptr(n_steps + 1, 0), tgt_tile, tgt_row, tgt_pair_ptr(1, 0), pair_a, pair_b, pair_src;
     double chol_flops = 0.0;
-    for (int k = 0; k < NT; ++k) {
-        diag_tile[k] = tile_map[(size_t)k * NT + k];
-        pre_tile[k] = k > 0 ? tile_map[(size_t)k * NT + (k - 1)] : -1;
-        row_ptr[k] = (int)row_tile.size();
-        for (int j = 0; j < k; ++j) if (tile_map[(size_t)k * NT + j] >= 0) { row_tile.push_back(tile_map[(size_t)k * NT + j]); row_col.push_back(j); }
+    {
+        std::vector<std::vector<size_t>> by_step(n_steps);
+        for (size_t u = 0; u < upd_i.size(); ++u) {
+            const int i = upd_i[u], j = upd_j[u], q = upd_k[u];
+            if (i == j && level[q] == level[i] - 1) continue; // pre-update, done by the factorising workgroup
+            by_step[level[q] + 1].push_back(u);
+        }
+        for (int st = 0; st < n_steps; ++st) {
+            h_tgt_ptr[st] = (int)tgt_tile.size();
+            auto& v = by_step[st];
+            std::stable_sort(v.begin(), v.end(), [&](size_t x, size_t y) {
+                const int tx = tile_map[(size_t)upd_i[x] * NT + upd_j[x]], ty = tile_map[(size_t)upd_i[y] * NT + upd_j[y]];
+                return tx != ty ? tx < ty : upd_k[x] < upd_k[y];
+            });
+            int cur = -1;
+            for (size_t w = 0; w < v.size(); ++w) {
+                const size_t u = v[w];
+                const int tt = tile_map[(size_t)upd_i[u] * NT + upd_j[u]];
+                if (tt != cur) {
+                    tgt_tile.push_back(tt);
+                    tgt_row.push_back(upd_i[u] == upd_j[u] ? upd_i[u] : -1);
+                    tgt_pair_ptr.push_back(tgt_pair_ptr.back());
+                    cur = tt;
+                }
+                pair_a.push_back(tile_map[(size_t)upd_i[u] * NT + upd_k[u]]);
+                pair_b.push_back(tile_map[(size_t)upd_j[u] * NT + upd_k[u]]);
+                pair_src.push_back(upd_k[u]);
+                tgt_pair_ptr.back()++;
+            }
+        }
+        h_tgt_ptr[n_steps] = (int)tgt_tile.size();
         const double t3 = (double)TS * TS * TS;
-        chol_flops += t3 / 3.0 + t3 * (h_col_ptr[k + 1] - h_col_ptr[k]) + 2.0 * t3 * (h_upd_ptr[k + 1] - h_upd_ptr[k]) + (pre_tile[k] >= 0 ? 2.0 * t3 : 0.0);
+        chol_flops = t3 / 3.0 * NT + t3 * (double)col_rows.size() + 2.0 * t3 * (double)upd_i.size();
     }
-    row_ptr[NT] = (int)row_tile.size();
+    // trsm items per step
+    std::vector<int> h_trsm_ptr(n_steps + 1, 0), st_tile, st_col;
+    for (int st = 0; st < n_steps; ++st) {
+        h_trsm_ptr[st] = (int)st_tile.size();
+        for (int q = h_step_ptr[st]; q < h_step_ptr[st + 1]; ++q) {
+            const int c = step_col[q];
+            for (int w = h_col_ptr[c]; w < h_col_ptr[c + 1]; ++w) { st_tile.push_back(trsm_tile[w]); st_col.push_back(c); }
+        }
+    }
+    h_trsm_ptr[n_steps] = (int)st_tile.size();
 
     // ---- Schur decomposition: always on 48 x 48 sub-tiles (8 poses x 8 poses), whatever TS is ----
     // item  = (landmark, row chunk cX, column chunk cY): the poses of the landmark in either chunk as
@@ -564,22 +660,25 @@ int build_structure(svi_ba* ba)
     if (o.n_ranks > 1) SVI_TRY(dev_alloc(ba, (size_t)3 * Ltot, &ba->lm_all));
 
     CholPlan& p = ba->plan;
-    p.TS = TS; p.NT = NT;
-    ba->h_col_ptr = h_col_ptr; ba->h_upd_ptr = h_upd_ptr; ba->h_diag_tile = diag_tile; ba->h_pre_tile = pre_tile;
-    p.h_col_ptr = ba->h_col_ptr.data(); p.h_upd_ptr = ba->h_upd_ptr.data(); p.h_diag_tile = ba->h_diag_tile.data();
-    p.h_pre_tile = ba->h_pre_tile.data();
+    p.TS = TS; p.NT = NT; p.n_steps = n_steps;
+    ba->h_step_ptr = h_step_ptr; ba->h_tgt_ptr = h_tgt_ptr; ba->h_trsm_ptr = h_trsm_ptr;
+    p.h_step_ptr = ba->h_step_ptr.data(); p.h_tgt_ptr = ba->h_tgt_ptr.data(); p.h_trsm_ptr = ba->h_trsm_ptr.data();
     SVI_TRY(dev_upload(ba, h_col_ptr, &p.col_ptr));
     SVI_TRY(dev_upload(ba, trsm_tile, &p.trsm_tile));
     SVI_TRY(dev_upload(ba, trsm_row, &p.trsm_row));
-    SVI_TRY(dev_upload(ba, h_upd_ptr, &p.upd_ptr));
-    SVI_TRY(dev_upload(ba, upd_a, &p.upd_a));
-    SVI_TRY(dev_upload(ba, upd_b, &p.upd_b));
-    SVI_TRY(dev_upload(ba, upd_c, &p.upd_c));
-    SVI_TRY(dev_upload(ba, upd_i, &p.upd_row));
+    SVI_TRY(dev_upload(ba, step_col, &p.step_col));
     SVI_TRY(dev_upload(ba, diag_tile, &p.diag_tile));
-    SVI_TRY(dev_upload(ba, row_ptr, &p.row_ptr));
-    SVI_TRY(dev_upload(ba, row_tile, &p.row_tile));
-    SVI_TRY(dev_upload(ba, row_col, &p.row_col));
+    SVI_TRY(dev_upload(ba, pre_ptr, &p.pre_ptr));
+    SVI_TRY(dev_upload(ba, pre_tile, &p.pre_tile));
+    SVI_TRY(dev_upload(ba, pre_col, &p.pre_col));
+    SVI_TRY(dev_upload(ba, tgt_tile, &p.tgt_tile));
+    SVI_TRY(dev_upload(ba, tgt_row, &p.tgt_row));
+    SVI_TRY(dev_upload(ba, tgt_pair_ptr, &p.tgt_pair_ptr));
+    SVI_TRY(dev_upload(ba, pair_a, &p.pair_a));
+    SVI_TRY(dev_upload(ba, pair_b, &p.pair_b));
+    SVI_TRY(dev_upload(ba, pair_src, &p.pair_src));
+    SVI_TRY(dev_upload(ba, st_tile, &p.st_tile));
+    SVI_TRY(dev_upload(ba, st_col, &p.st_col));
 
     SVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&ba->h_scal), 16 * sizeof(double)));
     SVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&ba->h_status), sizeof(int) * 4));
@@ -594,7 +693,7 @@ int build_structure(svi_ba* ba)
     st.n_edges_proj = Etot; st.n_edges_proj_local = E;
     st.n_edges_se3 = (int64_t)ba->se3.size(); st.n_edges_accel = (int64_t)ba->acc.size(); st.n_edges_lmlm = (int64_t)ba->lmlm.size();
     st.n_schur_tiles = n_jobs; st.n_window_blocks = total_pairs;
-    st.chol_n = n; st.chol_tile = TS; st.chol_tiles_nnz = n_tiles;
+    st.chol_n = n; st.chol_tile = TS; st.chol_tiles_nnz = n_tiles; st.chol_steps = n_steps;
     st.reduce_doubles = d.red_count;
     st.chol_flops = chol_flops;
     return SVI_OK;
@@ -768,6 +867,7 @@ void svi_ba_options_default(svi_ba_options* o)
     o->max_depth_xyz_l2 = 10.0; o->max_depth_uvdepth_l2 = 50.0; o->max_depth_uvdisp_l2 = 10000.0; o->sane_position_l2 = 1e12;
     o->n_ranks = 1;
     o->chol_tile = 96;
+    o->chol_order = 0;
 }
 
 int svi_ba_create(const svi_ba_options* o, svi_ba** out)
@@ -1260,6 +1360,10 @@ int svi_ba_debug_reduced_system(svi_ba* ba, double lambda, double* S, double* g,
     if (NT) SVI_HIP(hipMemcpyAsync(gv.data(), d.g, sizeof(double) * gv.size(), hipMemcpyDeviceToHost, ba->stream));
     if (NT) SVI_HIP(hipMemcpyAsync(tmap.data(), d.tile_map, sizeof(int) * tmap.size(), hipMemcpyDeviceToHost, ba->stream));
     SVI_HIP(hipStreamSynchronize(ba->stream));
+    // the tap reports the system in NATURAL free-pose order (ascending id), whatever elimination order is in use
+    std::vector<int64_t> nat(n);
+    for (int64_t a = 0; a < (int64_t)d.Pf; ++a)
+        for (int c = 0; c < 6; ++c) nat[6 * (int64_t)ba->red_perm[a] + c] = 6 * a + c;
     for (int64_t i = 0; i < n * n; ++i) S[i] = 0.0;
     for (int ti = 0; ti < NT; ++ti)
         for (int tj = 0; tj <= ti; ++tj) {
@@ -1270,10 +1374,10 @@ int svi_ba_debug_reduced_system(svi_ba* ba, double lambda, double* S, double* g,
                     const int64_t R = (int64_t)ti * TS + r, Cc = (int64_t)tj * TS + c;
                     if (R >= n || Cc >= n || Cc > R) continue;
                     const double v = tiles[(size_t)t * TS * TS + (size_t)r * TS + c];
-                    S[R * n + Cc] = v; S[Cc * n + R] = v;
+                    S[nat[R] * n + nat[Cc]] = v; S[nat[Cc] * n + nat[R]] = v;
                 }
         }
-    for (int64_t i = 0; i < n; ++i) { S[i * n + i] += lambda; g[i] = gv[i]; }
+    for (int64_t i = 0; i < n; ++i) { S[nat[i] * n + nat[i]] += lambda; g[nat[i]] = gv[i]; }
     return SVI_OK;
 }
 

@@ -61,7 +61,8 @@ struct svi_ba {
     // host mirrors of the structure
     std::vector<int> pose_order;    // slot -> index into poses
     std::vector<int> lm_order;      // global landmark slot -> index into lms
-    std::vector<int> h_col_ptr, h_upd_ptr, h_diag_tile, h_pre_tile;
+    std::vector<int> h_step_ptr, h_tgt_ptr, h_trsm_ptr;
+    std::vector<int> red_perm;      // natural reduced pose index -> elimination (reduced) index
     int L0 = 0, L1 = 0;             // this rank's landmark slots [L0, L1)
     int64_t E_total = 0;
     svi_ba_stats stats{};

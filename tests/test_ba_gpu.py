@@ -132,6 +132,31 @@ def test_full_schedule_medium_tile48(svi, oracle):
     assert _rel(Tg[:, 9:], To[:, 9:]) < REL and np.abs(Tg[:, :9] - To[:, :9]).max() < REL and _rel(pg, po) < REL
 
 
+@pytest.mark.parametrize("tile", [48, 96])
+def test_elimination_orders_agree(svi, tile):
+    """nested-dissection order (independent chains, level-scheduled launches) against the natural single chain:
+    same reduced system (the debug tap reports natural order), same LM trajectory to rounding"""
+    prob = synth.make_ba_problem(120, 6000, 50000, seed=5)
+    res = {}
+    for order in (0, 1):
+        g, _ = _make(svi.BundleAdjuster, prob, chol_tile=tile, chol_order=order)
+        g.initialize()
+        S, gv = g.reduced_system(1e-3)
+        n_it = g.optimize(6)
+        _, T = g.get_poses()
+        _, p = g.get_landmarks()
+        st = g.stats()
+        res[order] = (S, gv, n_it, T, p, g.last_plain_chi2, int(st.chol_steps), int(st.chol_tiles_nnz), int(st.chol_n))
+        g.close()
+    a, b = res[0], res[1]
+    assert np.abs(a[0] - b[0]).max() <= 1e-9 * np.abs(b[0]).max() and np.abs(a[1] - b[1]).max() <= 1e-9 * np.abs(b[1]).max()
+    assert a[2] == b[2]
+    assert np.abs(a[3] - b[3]).max() < 1e-8 and _rel(a[4], b[4]) < 1e-8 and abs(a[5] - b[5]) <= 1e-9 * b[5]
+    nt = -(-a[8] // tile)
+    assert b[6] == nt                       # natural order: one chain, one level per tile column
+    assert a[6] < b[6], (a[6], b[6])        # nested dissection: fewer launches on the critical path
+
+
 def test_c3_first_block_parity(svi, oracle):
     """BASELINE config 3 (100 KF / 20 k landmarks / 150 k edges): optimize(1) + optimize(10)."""
     prob = synth.make_c3()
