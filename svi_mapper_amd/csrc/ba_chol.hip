@@ -479,62 +479,83 @@ __device__ void gemm_target_block(double* __restrict__ S, const double* __restri
 // the rows of each tile: all its loads of a tile are issued together (constant trip count), partial sums meet in LDS.
 // ---------------------------------------------------------------------------------------------
 template <int TS>
-__global__ __launch_bounds__(kBlock) void k_back_solve(const double* __restrict__ Lt, const double* __restrict__ Linv, double* x, CholPlan p,
-                                                       const int* __restrict__ cols, const int* status)
+__global__ __launch_bounds__(kPotrfThreads) void k_back_solve(const double* __restrict__ Lt, const double* __restrict__ Linv, double* x, CholPlan p,
+                                                              const int* __restrict__ cols, const int* status)
 {
-    constexpr int RP = kBlock / TS, RN = (TS + RP - 1) / RP; // row parts per column, rows per part
+    constexpr int NW = kPotrfThreads / 64;
+    __shared__ double s_part[NW][TS];
+    __shared__ double s_x[NW][TS];
     __shared__ double s_acc[TS];
-    __shared__ double s_xi[TS];
-    __shared__ double s_part[RP][TS];
-    const int tid = threadIdx.x;
-    const int c = tid % TS, part = tid / TS;
-    const bool active = part < RP;
-    const int r0 = part * RN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (*status != 0) return;
     const int k = cols[blockIdx.x];
-    if (tid < TS) s_acc[tid] = x[k * TS + tid];
-    for (int q = p.col_ptr[k]; q < p.col_ptr[k + 1]; ++q) {
-        const double* L = Lt + (size_t)p.trsm_tile[q] * TS * TS;
-        double v[RN];
-        if (active) {
+    const int q0 = p.col_ptr[k], nq = p.col_ptr[k + 1] - q0;
+    // (1) sum_{i>k} L_ik' x_i : the sub-diagonal tiles of the column are spread over the waves, lane = column of the
+    //     tile (and column + 64), rows streamed with the x_i entry broadcast from LDS
+    double a0 = 0.0, a1 = 0.0;
+    constexpr int RB = 24, NRB = TS / RB; // a work unit = RB rows of one tile; units go round the waves
+    static_assert(TS % RB == 0 && RB % 8 == 0, "tile edge");
+    const int c0 = lane < TS ? lane : TS - 1, c1 = lane + 64 < TS ? lane + 64 : TS - 1;
+    for (int u = wave; u < nq * NRB; u += NW) {
+        const int q = u / NRB, rb = u % NRB;
+        const double* L = Lt + (size_t)p.trsm_tile[q0 + q] * TS * TS + (size_t)rb * RB * TS;
+        const double* xi = x + (size_t)p.trsm_row[q0 + q] * TS + rb * RB;
+        __builtin_amdgcn_wave_barrier();
+        if (lane < RB) s_x[wave][lane] = xi[lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        // unconditional, batched loads (8 rows in flight per lane); lanes beyond the tile read a clamped column
 #pragma unroll
-            for (int i = 0; i < RN; ++i) v[i] = (r0 + i < TS) ? L[(r0 + i) * TS + c] : 0.0;
-        }
-        if (tid < TS) s_xi[tid] = x[p.trsm_row[q] * TS + tid];
-        __syncthreads();
-        if (active) {
-            double s = 0.0;
+        for (int r8 = 0; r8 < RB; r8 += 8) {
+            double v0[8], v1[8];
 #pragma unroll
-            for (int i = 0; i < RN; ++i) s = fma(v[i], (r0 + i < TS) ? s_xi[r0 + i] : 0.0, s);
-            s_part[part][c] = s;
-        }
-        __syncthreads();
-        if (tid < TS) {
-            double s = 0.0;
+            for (int w = 0; w < 8; ++w) { v0[w] = L[(r8 + w) * TS + c0]; if (TS > 64) v1[w] = L[(r8 + w) * TS + c1]; }
 #pragma unroll
-            for (int q2 = 0; q2 < RP; ++q2) s += s_part[q2][tid];
-            s_acc[tid] -= s;
+            for (int w = 0; w < 8; ++w) {
+                const double xr = s_x[wave][r8 + w];
+                a0 = fma(v0[w], xr, a0);
+                if (TS > 64) a1 = fma(v1[w], xr, a1);
+            }
         }
     }
-    const double* X = Linv + (size_t)k * TS * TS;
-    double v[RN];
-    if (active) {
-#pragma unroll
-        for (int i = 0; i < RN; ++i) v[i] = (r0 + i < TS && r0 + i >= c) ? X[(r0 + i) * TS + c] : 0.0;
-    }
-    __syncthreads();
-    if (active) {
-        double s = 0.0;
-#pragma unroll
-        for (int i = 0; i < RN; ++i) s = fma(v[i], (r0 + i < TS) ? s_acc[r0 + i] : 0.0, s);
-        s_part[part][c] = s;
-    }
+    if (lane < TS) s_part[wave][lane] = a0;
+    if (lane + 64 < TS) s_part[wave][lane + 64] = a1;
     __syncthreads();
     if (tid < TS) {
-        double s = 0.0;
+        double sum = 0.0;
 #pragma unroll
-        for (int q2 = 0; q2 < RP; ++q2) s += s_part[q2][tid];
-        x[k * TS + tid] = s;
+        for (int w = 0; w < NW; ++w) sum += s_part[w][tid];
+        s_acc[tid] = x[k * TS + tid] - sum;
+    }
+    __syncthreads();
+    // (2) x_k = Linv_kk' s_acc (Linv is lower triangular): rows split over the waves
+    constexpr int RW = (TS + NW - 1) / NW;
+    const double* X = Linv + (size_t)k * TS * TS;
+    double b0 = 0.0, b1 = 0.0;
+    {
+        double v0[RW], v1[RW];
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int r = wave * RW + rr < TS ? wave * RW + rr : TS - 1;
+            v0[rr] = X[r * TS + c0];
+            if (TS > 64) v1[rr] = X[r * TS + c1];
+        }
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int r = wave * RW + rr;
+            const double sr = r < TS ? s_acc[r < TS ? r : 0] : 0.0;
+            b0 = fma(r >= c0 ? v0[rr] : 0.0, sr, b0);   // Linv is lower triangular
+            if (TS > 64) b1 = fma(r >= c1 ? v1[rr] : 0.0, sr, b1);
+        }
+    }
+    if (lane < TS) s_part[wave][lane] = b0;
+    if (lane + 64 < TS) s_part[wave][lane + 64] = b1;
+    __syncthreads();
+    if (tid < TS) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += s_part[w][tid];
+        x[k * TS + tid] = sum;
     }
 }
 
@@ -567,7 +588,7 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
     }
     for (int st = p.n_steps - 1; st >= 0; --st) {
         const int c0 = p.h_step_ptr[st], nc = p.h_step_ptr[st + 1] - c0;
-        hipLaunchKernelGGL(k_back_solve<TS>, dim3(nc), dim3(kBlock), 0, s, Lt, Linv, x, p, p.step_col + c0, status);
+        hipLaunchKernelGGL(k_back_solve<TS>, dim3(nc), dim3(kPotrfThreads), 0, s, Lt, Linv, x, p, p.step_col + c0, status);
     }
     return 0;
 }

@@ -124,6 +124,9 @@ struct BaDev {
     int add_pose_terms;       // rank 0 adds Hpp / bp / odometry blocks
 
     // LM scalars on the device
+    double* aux_part;  // [aux_blocks][2] chi2 partials of the pose-only edges
+    int*    aux_count; // arrival counter of k_aux_edges (zero between launches)
+    int     aux_blocks;
     double* scal;   // [8]: 0 chi_robust(trial) 1 chi_plain(trial) 2 scale_lm 3 scale_pose 4 spare...
 };
 

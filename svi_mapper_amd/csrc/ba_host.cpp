@@ -160,37 +160,89 @@ int build_structure(svi_ba* ba)
     ba->red_perm.resize(Pf);
     std::iota(ba->red_perm.begin(), ba->red_perm.end(), 0);
     {
-        int TSo = o.chol_tile > 0 ? o.chol_tile : 96;
+        const int TSo = o.chol_tile > 0 ? o.chol_tile : 96;
         const int PBo = TSo / 6;
-        int span = 0; // largest |r_i - r_j| over coupled free poses (natural reduced indices)
-        if (o.chol_order == 0 && PBo > 0 && Pf >= 6 * PBo) {
-            std::vector<int> lo(Ltot, INT32_MAX), hi(Ltot, -1);
+        const int NTo = PBo > 0 ? (Pf + PBo - 1) / PBo : 0;
+        if (o.chol_order == 0 && PBo > 0 && NTo >= 6) {
+            // free poses of every landmark (natural reduced indices), pose-pose edges
+            std::vector<std::vector<int>> lm_red(Ltot);
             for (const HProj& e : ba->proj) {
                 const int r = pose_red[pose_slot[e.pose]];
-                if (r >= 0 && !ba->lms[e.lm].fixed) { lo[e.lm] = std::min(lo[e.lm], r); hi[e.lm] = std::max(hi[e.lm], r); }
+                if (r >= 0 && !ba->lms[e.lm].fixed) lm_red[e.lm].push_back(r);
             }
-            for (int l = 0; l < Ltot; ++l) if (hi[l] >= 0) span = std::max(span, hi[l] - lo[l]);
+            int span = 0; // largest |r_i - r_j| over coupled free poses
+            for (auto& v : lm_red) {
+                if (v.empty()) continue;
+                const auto mm = std::minmax_element(v.begin(), v.end());
+                span = std::max(span, *mm.second - *mm.first);
+            }
+            std::vector<std::pair<int, int>> pp;
             for (const HSe3& e : ba->se3) {
                 const int ri = pose_red[pose_slot[e.i]], rj = pose_red[pose_slot[e.j]];
-                if (ri >= 0 && rj >= 0) span = std::max(span, std::abs(ri - rj));
+                if (ri >= 0 && rj >= 0) { pp.push_back({ri, rj}); span = std::max(span, std::abs(ri - rj)); }
             }
-        }
-        const int rem = Pf % PBo;
-        const int sep = ((std::max(span, 1) + PBo - 1) / PBo) * PBo;                                        // inner separators
-        const int sep_top = rem == 0 ? sep : rem + PBo * ((std::max(span - rem, 0) + PBo - 1) / PBo);     // absorbs the remainder
-        if (span > 0 && Pf >= sep_top + 4 * PBo) {
-            std::vector<std::pair<int, int>> pieces; // natural ranges in elimination order
-            std::function<void(int, int, int)> rec = [&](int a, int b, int w) {
-                const int len = b - a;
-                if (len < w + 2 * PBo) { if (len > 0) pieces.push_back({a, b}); return; }
-                const int left = PBo * (((len - w) / PBo) / 2);
-                rec(a, a + left, sep);
-                rec(a + left + w, b, sep);
-                pieces.push_back({a + left, a + left + w});
+            const int rem = Pf % PBo;
+            // elimination order for separators of `w` tiles; false if the sequence is too short for it
+            auto make_perm = [&](int w, std::vector<int>& perm) {
+                const int sep = w * PBo;
+                const int sep_top = rem == 0 ? sep : rem + PBo * ((std::max(sep - rem, 0) + PBo - 1) / PBo); // absorbs the remainder
+                if (Pf < sep_top + 4 * PBo) return false;
+                std::vector<std::pair<int, int>> pieces; // natural ranges in elimination order
+                std::function<void(int, int, int)> rec = [&](int a, int b, int wd) {
+                    const int len = b - a;
+                    if (len < wd + 2 * PBo) { if (len > 0) pieces.push_back({a, b}); return; }
+                    const int left = PBo * (((len - wd) / PBo) / 2);
+                    rec(a, a + left, sep);
+                    rec(a + left + wd, b, sep);
+                    pieces.push_back({a + left, a + left + wd});
+                };
+                rec(0, Pf, sep_top);
+                perm.assign(Pf, 0);
+                int pos = 0;
+                for (auto& pc : pieces) for (int r = pc.first; r < pc.second; ++r) perm[r] = pos++;
+                return true;
             };
-            rec(0, Pf, sep_top);
-            int pos = 0;
-            for (auto& pc : pieces) for (int r = pc.first; r < pc.second; ++r) ba->red_perm[r] = pos++;
+            // dependency levels (= launches on the critical path) and filled tiles of an order
+            auto analyse = [&](const std::vector<int>& perm, int& depth, int& tiles) {
+                std::vector<uint8_t> z((size_t)NTo * NTo, 0);
+                for (int t = 0; t < NTo; ++t) z[(size_t)t * NTo + t] = 1;
+                std::vector<int> v;
+                for (auto& lr : lm_red) {
+                    v.clear();
+                    for (int r : lr) v.push_back(perm[r] / PBo);
+                    std::sort(v.begin(), v.end());
+                    v.erase(std::unique(v.begin(), v.end()), v.end());
+                    for (size_t x = 0; x < v.size(); ++x) for (size_t y = 0; y <= x; ++y) z[(size_t)v[x] * NTo + v[y]] = 1;
+                }
+                for (auto& e : pp) { const int x = perm[e.first] / PBo, y = perm[e.second] / PBo; z[(size_t)std::max(x, y) * NTo + std::min(x, y)] = 1; }
+                std::vector<int> rows;
+                for (int k = 0; k < NTo; ++k) {
+                    rows.clear();
+                    for (int i = k + 1; i < NTo; ++i) if (z[(size_t)i * NTo + k]) rows.push_back(i);
+                    for (size_t x = 0; x < rows.size(); ++x) for (size_t y = 0; y <= x; ++y) z[(size_t)rows[x] * NTo + rows[y]] = 1;
+                }
+                std::vector<int> lev(NTo, 0);
+                depth = 0; tiles = 0;
+                for (int c = 0; c < NTo; ++c) {
+                    for (int q = 0; q < c; ++q) if (z[(size_t)c * NTo + q]) { lev[c] = std::max(lev[c], lev[q] + 1); }
+                    for (int q = 0; q <= c; ++q) tiles += z[(size_t)c * NTo + q];
+                    depth = std::max(depth, lev[c] + 1);
+                }
+            };
+            // candidates: natural order and separators of 1 .. ceil(span / tile) tiles (a separator narrower than the
+            // longest track still gives a valid order - the few tracks that cross it only add dependencies); keep the
+            // order with the fewest levels, then the fewest tiles
+            std::vector<int> best = ba->red_perm, cand;
+            int best_depth = 0, best_tiles = 0;
+            analyse(best, best_depth, best_tiles);
+            const int wmax = std::max(1, (span + PBo - 1) / PBo);
+            for (int w = 1; w <= wmax && w <= 8; ++w) {
+                if (!make_perm(w, cand)) break;
+                int dp = 0, tl = 0;
+                analyse(cand, dp, tl);
+                if (dp < best_depth || (dp == best_depth && tl < best_tiles)) { best = cand; best_depth = dp; best_tiles = tl; }
+            }
+            ba->red_perm = best;
             for (int sl = 0; sl < Pn; ++sl) if (pose_red[sl] >= 0) pose_red[sl] = ba->red_perm[pose_red[sl]];
             for (int sl = 0; sl < Pn; ++sl) if (pose_red[sl] >= 0) red_slot[pose_red[sl]] = sl;
         }
@@ -542,7 +594,8 @@ int build_structure(svi_ba* ba)
     for (int i = 0; i < n_items; ++i) {
         it_pack[4 * i] = items[i].lm; it_pack[4 * i + 1] = items[i].a0; it_pack[4 * i + 2] = items[i].b0; it_pack[4 * i + 3] = items[i].masks;
     }
-    const int target = (int)std::min<int64_t>(1024, std::max<int64_t>(48, n_items / 1536));
+    const int tdiv = getenv("SVI_SCHUR_DIV") ? atoi(getenv("SVI_SCHUR_DIV")) : 1536;
+    const int target = (int)std::min<int64_t>(1024, std::max<int64_t>(16, n_items / tdiv));
     std::vector<int> job_item0(1, 0), job_sub;
     for (int i = 0; i < n_items;) {
         const int sub = items[i].sub;
@@ -657,6 +710,10 @@ int build_structure(svi_ba* ba)
     SVI_TRY(dev_upload(ba, sub_aux_ref, &d.sub_aux_ref));
     d.add_pose_terms = (o.rank == 0) ? 1 : 0;
     SVI_TRY(dev_alloc(ba, 16, &d.scal));
+    d.aux_blocks = std::max(1, (std::max(d.n_se3, d.n_accel) + 63) / 64);
+    SVI_TRY(dev_alloc(ba, (size_t)2 * d.aux_blocks, &d.aux_part));
+    SVI_TRY(dev_alloc(ba, 1, &d.aux_count));
+    SVI_HIP(hipMemsetAsync(d.aux_count, 0, sizeof(int), ba->stream));
     if (o.n_ranks > 1) SVI_TRY(dev_alloc(ba, (size_t)3 * Ltot, &ba->lm_all));
 
     CholPlan& p = ba->plan;

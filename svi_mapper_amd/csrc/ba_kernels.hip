@@ -303,13 +303,15 @@ __global__ __launch_bounds__(kBlock) void k_linearize_pose(BaDev d, int cur)
 // pose-only edges (odometry EdgeSE3, gravity EdgeSE3LinearAcceleration): a single workgroup,
 // LINEARIZE: also the quadratic forms.  Writes aux chi2 (robust, plain) to d.scal[6], d.scal[7].
 // ---------------------------------------------------------------------------------------------
+constexpr int kAuxThreads = 64; // one edge per lane, one wavefront per workgroup: the edges spread over many CUs
+
 template <bool LINEARIZE>
-__global__ __launch_bounds__(kBlock) void k_aux_edges(BaDev d, int which)
+__global__ __launch_bounds__(kAuxThreads) void k_aux_edges(BaDev d, int which)
 {
-    __shared__ double s_red[2 * 4];
     const double* __restrict__ pose = d.pose[which];
     double part[2] = {0.0, 0.0};
-    for (int k = threadIdx.x; k < d.n_se3; k += kBlock) {
+    const int gid = blockIdx.x * kAuxThreads + threadIdx.x;
+    for (int k = gid; k < d.n_se3; k += gridDim.x * kAuxThreads) {
         const int si = d.se3_i[k], sj = d.se3_j[k];
         double e[6], Ji[36], Jj[36], O[36];
         se3_edge_eval(pose + 12 * si, pose + 12 * sj, d.se3_Z + 12 * k, e, LINEARIZE ? Ji : nullptr, Jj);
@@ -352,7 +354,7 @@ __global__ __launch_bounds__(kBlock) void k_aux_edges(BaDev d, int which)
             }
         }
     }
-    for (int k = threadIdx.x; k < d.n_accel; k += kBlock) {
+    for (int k = gid; k < d.n_accel; k += gridDim.x * kAuxThreads) {
         const int s = d.acc_pose[k];
         const double* R = pose + 12 * s;
         const double v[3] = {d.acc_a[3 * k], d.acc_a[3 * k + 1], d.acc_a[3 * k + 2]};
@@ -388,8 +390,28 @@ __global__ __launch_bounds__(kBlock) void k_aux_edges(BaDev d, int which)
             }
         }
     }
-    block_sum<2>(part, s_red);
-    if (threadIdx.x == 0) { d.scal[6] = part[0]; d.scal[7] = part[1]; }
+    // per-workgroup partials, then the LAST workgroup to arrive adds them in workgroup order (deterministic)
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+        for (int off = 32; off > 0; off >>= 1) part[q] += __shfl_xor(part[q], off);
+    __shared__ int s_last;
+    if (threadIdx.x == 0) {
+        d.aux_part[2 * blockIdx.x] = part[0];
+        d.aux_part[2 * blockIdx.x + 1] = part[1];
+        __threadfence();
+        s_last = (atomicAdd(d.aux_count, 1) == (int)gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (s_last && threadIdx.x == 0) {
+        __threadfence();
+        double r0 = 0.0, r1 = 0.0;
+        for (unsigned b = 0; b < gridDim.x; ++b) {
+            r0 += __builtin_nontemporal_load(d.aux_part + 2 * b);
+            r1 += __builtin_nontemporal_load(d.aux_part + 2 * b + 1);
+        }
+        d.scal[6] = r0; d.scal[7] = r1;
+        *d.aux_count = 0;
+    }
 }
 
 // H_pp / b_p of every free pose = sum of its chunk partials (fixed order) + its pose-only edges.
@@ -603,20 +625,20 @@ __global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
             }
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
-                // top rows: [ M | -M Kb ]
+                // top rows: [ M | -M Kb ]   (each cross-product term is two fused multiply-adds into the accumulator)
                 acc[6 * r]     += M[3 * r];
                 acc[6 * r + 1] += M[3 * r + 1];
                 acc[6 * r + 2] += M[3 * r + 2];
-                acc[6 * r + 3] -= M[3 * r + 1] * b2 - M[3 * r + 2] * b1;
-                acc[6 * r + 4] -= M[3 * r + 2] * b0 - M[3 * r] * b2;
-                acc[6 * r + 5] -= M[3 * r] * b1 - M[3 * r + 1] * b0;
+                acc[6 * r + 3] = fma(M[3 * r + 2], b1, fma(-M[3 * r + 1], b2, acc[6 * r + 3]));
+                acc[6 * r + 4] = fma(M[3 * r], b2, fma(-M[3 * r + 2], b0, acc[6 * r + 4]));
+                acc[6 * r + 5] = fma(M[3 * r + 1], b0, fma(-M[3 * r], b1, acc[6 * r + 5]));
                 // bottom rows: [ Ka M | -Ka M Kb ]
                 acc[6 * (3 + r)]     += KM[3 * r];
                 acc[6 * (3 + r) + 1] += KM[3 * r + 1];
                 acc[6 * (3 + r) + 2] += KM[3 * r + 2];
-                acc[6 * (3 + r) + 3] -= KM[3 * r + 1] * b2 - KM[3 * r + 2] * b1;
-                acc[6 * (3 + r) + 4] -= KM[3 * r + 2] * b0 - KM[3 * r] * b2;
-                acc[6 * (3 + r) + 5] -= KM[3 * r] * b1 - KM[3 * r + 1] * b0;
+                acc[6 * (3 + r) + 3] = fma(KM[3 * r + 2], b1, fma(-KM[3 * r + 1], b2, acc[6 * (3 + r) + 3]));
+                acc[6 * (3 + r) + 4] = fma(KM[3 * r], b2, fma(-KM[3 * r + 2], b0, acc[6 * (3 + r) + 4]));
+                acc[6 * (3 + r) + 5] = fma(KM[3 * r + 1], b0, fma(-KM[3 * r], b1, acc[6 * (3 + r) + 5]));
             }
             if (diag && i == j) { // g_a += H_pl,a Hinv b_l = [ -w ; -Ka w ],  w = T b_l
                 const double w0 = T[0] * Hi[6] + T[1] * Hi[7] + T[2] * Hi[8];
@@ -889,11 +911,11 @@ void ba_linearize_pose(const BaDev& d, int cur, void* st)
 }
 void ba_linearize_aux(const BaDev& d, int cur, int, void* st)
 {
-    hipLaunchKernelGGL((k_aux_edges<true>), dim3(1), dim3(kBlock), 0, S_(st), d, cur);
+    hipLaunchKernelGGL((k_aux_edges<true>), dim3(d.aux_blocks), dim3(kAuxThreads), 0, S_(st), d, cur);
 }
 void ba_chi2_aux(const BaDev& d, int which, int, void* st)
 {
-    hipLaunchKernelGGL((k_aux_edges<false>), dim3(1), dim3(kBlock), 0, S_(st), d, which);
+    hipLaunchKernelGGL((k_aux_edges<false>), dim3(d.aux_blocks), dim3(kAuxThreads), 0, S_(st), d, which);
 }
 void ba_pose_finalize(const BaDev& d, const int* red_slot, int rank, int n_ranks, void* st)
 {
