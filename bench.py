@@ -153,6 +153,16 @@ def bench_frontend(svi, reps=200):
     ll, rf = d(sc.last_left), d(sc.ref_desc)
     out["ragged_match_ms"] = timed(lambda: fm.get_match(ll, rf, seg, pool, 50, 100))
     out["ragged_match_candidates"] = int(plan.total)
+    # BRIEF extraction of the same frame's epipolar candidates (stand-in test-pair table, tests/brief_case.py)
+    import brief_case
+    br = temporal.BriefExtractor(brief_case.pattern(), matcher=fm.matcher, device=dev.index)
+    img = d(brief_case.image(ts.H, ts.W, 1))
+    out["brief_integral_ms"] = timed(lambda: br.set_image("left", img))
+    g_seg, samples, roi = fm.epipolar_samples(plan, 0)
+    kept = br("left", roi, g_seg, samples)
+    out["brief_extract_ms"] = timed(lambda: br("left", roi, g_seg, samples), 100)
+    out["brief_keypoints_in"] = int(samples.shape[0])
+    out["brief_keypoints_kept"] = int(kept[1].shape[0])
     # loop closure: 2000 query descriptors against 200 key frames x ~1500 descriptors
     nq, n_clouds = 2000, 200
     sizes = rng.integers(1000, 2000, n_clouds)

@@ -284,6 +284,27 @@ int svi_track_stereo_verify_dev(svi_matcher* m, const svi_track_stereo_params* p
                                 float* out_uv_other, double* out_xyz);
 
 /* ------------------------------------------------------------------------------------------
+ * BRIEF-256 extraction — replaces cv::xfeatures2d::BriefDescriptorExtractor::compute( image( roi ),
+ * keypoints, descriptors ) as called at CTriangulator.cpp:84,147,218,289 and CFundamentalMatcher.cpp:401,450,534,651,2345:
+ * integral image, key points within 28 px of the ROI border are dropped (KeyPointsFilter::runByImageBorder), 256
+ * comparisons of 9x9 box sums, test t -> byte t/8, bit 7 - t%8.  OpenCV's baked test pairs are not part of the reference
+ * tree: `pattern` is the caller's table, 256 x (y1, x1, y2, x2) in int8, each within [-24, 24] (generated_32.i order).
+ * ---------------------------------------------------------------------------------------- */
+typedef struct svi_brief svi_brief;
+int svi_brief_create(svi_matcher* m, const int8_t* pattern /* host, 1024 */, svi_brief** out);
+int svi_brief_destroy(svi_brief* b);
+/* integral image of one frame (side 0 = LEFT, 1 = RIGHT); image: device u8, `stride` bytes per row */
+int svi_brief_set_image_dev(svi_brief* b, int side, const uint8_t* image, int width, int height, int stride);
+/* debug / test tap: the (height+1) x (width+1) int32 integral image of a side, device to device */
+int svi_brief_integral_dev(svi_brief* b, int side, int32_t* out);
+/* roi: n x 4 i32 (x, y, w, h) = the cv::Rect of every pool; key points kp_uv[seg[i] .. seg[i+1]) in ROI coordinates.
+ * Outputs are compacted per ROI in input order: seg_out n+1, kp_out / desc_out with room for total_in rows (desc_out
+ * 4-byte aligned); *total_out (host, nullable; synchronises) = key points kept.  A ROI that does not lie inside the
+ * frame (cv::Mat::operator() would assert) or is not larger than 56 px keeps nothing. */
+int svi_brief_compute_dev(svi_brief* b, int side, const int32_t* roi, const int32_t* seg, const float* kp_uv, int n,
+                          int64_t total_in, int32_t* seg_out, float* kp_out, uint8_t* desc_out, int64_t* total_out);
+
+/* ------------------------------------------------------------------------------------------
  * Frame pose from the stage-1/2 matches — replaces CSolverStereoPosit::getTransformationWORLDtoLEFT
  * (src/optimization/CSolverStereoPosit.cpp:8-170): iteratively re-weighted Gauss-Newton on the
  * stereo reprojection error, the whole loop in ONE launch (no host round trip per iteration).

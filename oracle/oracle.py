@@ -106,6 +106,9 @@ def load(path=None):
     lib.orc_track_stereo_verify.argtypes = [vp, _u8p, _u8p, _u8p, _f32p, _f32p, C.c_int, _i32p, _u8p, _f32p, _i32p, _i32p, _i32p,
                                             _f32p, _f64p]
     lib.orc_track_handover.argtypes = [C.c_int, vp, _f32p, _i32p, C.c_int, _i32p, _f32p, _i32p, _f32p, _f32p, _f32p, _u8p]
+    lib.orc_brief_integral.argtypes = [_u8p, C.c_int, C.c_int, C.c_int, _i32p]
+    lib.orc_brief_compute.restype = C.c_int
+    lib.orc_brief_compute.argtypes = [_i32p, C.c_int, C.c_int, C.c_void_p, _i32p, _i32p, _f32p, C.c_int, _i32p, _f32p, _u8p]
     lib.orc_landmarks_optimize.argtypes = [vp, _f64p, _f64p, C.c_int, _i32p, _i32p, _f32p, _f32p, _f64p, C.c_int, _f64p, _i32p, _f64p, _i32p]
     lib.orc_stereo_posit.argtypes = [vp, _f64p, _f64p, _f64p, _f64p, _f32p, _f32p, _u8p, C.c_int, vp]
     if path.endswith("liboracle.so"):
@@ -609,7 +612,8 @@ class OracleFundamentalMatcher:
                 try:
                     found = detector(name, r["s2_" + name])
                     shifted = (found + np.float32(4) * kp).astype(np.float32)                     # :533
-                    kp_uv, desc = extractor(name, r["s2_ext_" + name], shifted)
+                    c = np.rint(r["s2_ext_" + name]).astype(np.float32)                        # cv::Rect( Point2f, Point2f )
+                    kp_uv, desc = extractor(name, np.array([c[0], c[1], c[2] - c[0], c[3] - c[1]], np.float32), shifted)
                     here, there = (last_l[i], last_r[i]) if side == 0 else (last_r[i], last_l[i])
                     seg = np.array([0, len(kp_uv)], np.int32)
                     idx, dist, st = match_ragged(here[None], None, seg, desc, 50, lib=self.lib)   # :540-545
@@ -720,3 +724,31 @@ def landmarks_optimize(prm, frame_P_left, frame_P_right, seg, meas_frame, uvl, u
     lib.orc_landmarks_optimize(C.byref(prm), _p(PL, _f64p), _p(PR, _f64p), len(PL), _p(seg, _i32p), _p(fr, _i32p), _p(ul, _f32p), _p(ur, _f32p),
                                _p(x, _f64p), n, _p(out, _f64p), _p(st, _i32p), _p(err, _f64p), _p(its, _i32p))
     return out, st, err, its
+
+
+# ------------------------------------------------------------------------------------------------
+# BRIEF-256 extraction (oracle_brief.c)
+# ------------------------------------------------------------------------------------------------
+def brief_integral(image, lib=None):
+    lib = lib or load()
+    img = np.ascontiguousarray(image, np.uint8)
+    h, w = img.shape
+    out = np.zeros((h + 1, w + 1), np.int32)
+    lib.orc_brief_integral(_p(img, _u8p), w, h, w, _p(out, _i32p))
+    return out
+
+
+def brief_compute(integral, pattern, roi, seg, kp_uv, lib=None):
+    """roi n x 4 (x, y, w, h; floats are truncated like cv::Rect does); -> (seg_out, kp_out, desc)"""
+    lib = lib or load()
+    h, w = integral.shape[0] - 1, integral.shape[1] - 1
+    pat = np.ascontiguousarray(pattern, np.int8).reshape(1024)
+    roi_i = np.ascontiguousarray(np.trunc(np.asarray(roi, np.float64)).astype(np.int32)).reshape(-1, 4)
+    seg, kp = _a(seg, np.int32), _a(kp_uv, np.float32, (-1, 2))
+    n = len(roi_i)
+    seg_out = np.zeros(n + 1, np.int32)
+    kp_out = np.zeros((max(len(kp), 1), 2), np.float32)
+    desc = np.zeros((max(len(kp), 1), 32), np.uint8)
+    kept = lib.orc_brief_compute(_p(integral, _i32p), w, h, pat.ctypes.data, _p(roi_i, _i32p), _p(seg, _i32p), _p(kp, _f32p), n, _p(seg_out, _i32p),
+                                 _p(kp_out, _f32p), _p(desc, _u8p))
+    return seg_out, kp_out[:kept], desc[:kept]

@@ -126,6 +126,11 @@ SIGNATURES = {
     "svi_match_ragged_dev": (C.c_int, [vp, vp, vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, vp, vp, vp]),
     "svi_track_stereo_verify_dev": (C.c_int, [vp, C.POINTER(TrackStereoParams), vp, vp, vp, vp, vp, C.c_int, vp, vp, vp,
                                               vp, vp, vp, vp, vp]),
+    "svi_brief_create": (C.c_int, [vp, vp, C.POINTER(vp)]),
+    "svi_brief_destroy": (C.c_int, [vp]),
+    "svi_brief_set_image_dev": (C.c_int, [vp, C.c_int, vp, C.c_int, C.c_int, C.c_int]),
+    "svi_brief_integral_dev": (C.c_int, [vp, C.c_int, vp]),
+    "svi_brief_compute_dev": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int64, vp, vp, vp, i64p]),
     "svi_posit_params_default": (None, [C.POINTER(PositParams)]),
     "svi_stereo_posit_dev": (C.c_int, [vp, C.POINTER(PositParams), f64p, f64p, f64p, vp, vp, vp, vp, C.c_int, C.POINTER(PositResult)]),
     "svi_landmark_params_default": (None, [C.POINTER(LandmarkParams)]),

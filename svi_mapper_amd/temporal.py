@@ -325,7 +325,8 @@ class FundamentalMatcher:
             c_rect = RECORD_DTYPE.fields["s2_" + name][1] // 4
             c_ext = RECORD_DTYPE.fields["s2_ext_" + name][1] // 4
             rect = rec32[todo][:, c_rect:c_rect + 4].contiguous()
-            ext = rec32[todo][:, c_ext:c_ext + 4].contiguous()
+            corners = torch.round(rec32[todo][:, c_ext:c_ext + 4])   # cv::Rect( Point2f, Point2f ): corners are cvRound()ed
+            ext = torch.stack([corners[:, 0], corners[:, 1], corners[:, 2] - corners[:, 0], corners[:, 3] - corners[:, 1]], 1).contiguous()
             seg_d, kp_d = detector(name, rect)
             owner = torch.repeat_interleave(torch.arange(todo.numel(), device=self.device), (seg_d[1:] - seg_d[:-1]).long())
             kp_shift = (kp_d + (4 * kp)[owner][:, None]).contiguous()                                   # :533
@@ -459,3 +460,68 @@ class LandmarkOptimizer:
                                                    _p(xyz), n, _p(out), _p(status), _p(err), _p(its)), "svi_landmarks_optimize_dev")
         torch.cuda.current_stream(self.device).wait_stream(self._ext)
         return out, status, err, its
+
+
+class BriefExtractor:
+    """cv::xfeatures2d::BriefDescriptorExtractor (32 bytes) on the MI355X with a caller-supplied test-pair table
+    (SURVEY.md §8f-4); an instance is the `extractor` callable the tracking cascades expect, so a frame is tracked
+    without leaving the device.  roi rows are the float arguments of cv::Rect( x, y, w, h ): truncated like the
+    implicit float -> int conversion does."""
+
+    def __init__(self, pattern, matcher=None, device=0):
+        self.matcher = matcher or HammingMatcher(device)
+        self._lib = _capi.load_library()
+        pat = np.ascontiguousarray(pattern, np.int8).reshape(1024)
+        h = C.c_void_p()
+        check(self._lib.svi_brief_create(self.matcher._h, pat.ctypes.data_as(C.c_void_p), C.byref(h)), "svi_brief_create")
+        self._h = h
+        self.device = torch.device("cuda", device)
+        self._ext = torch.cuda.ExternalStream(self.matcher.stream, device=self.device)
+        self._shape = [None, None]
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._lib.svi_brief_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_image(self, side, image):
+        """image: H x W uint8 CUDA tensor (rows may be strided)"""
+        s = 0 if side in (0, "left") else 1
+        if image.dtype != torch.uint8 or not image.is_cuda or image.dim() != 2 or image.stride(1) != 1:
+            raise ValueError("image must be a 2-D uint8 CUDA tensor with unit column stride")
+        self._ext.wait_stream(torch.cuda.current_stream(self.device))
+        check(self._lib.svi_brief_set_image_dev(self._h, s, _p(image), image.shape[1], image.shape[0], image.stride(0)), "svi_brief_set_image_dev")
+        torch.cuda.current_stream(self.device).wait_stream(self._ext)
+        self._shape[s] = (image.shape[0], image.shape[1])
+
+    def integral(self, side):
+        s = 0 if side in (0, "left") else 1
+        hh, ww = self._shape[s]
+        out = torch.empty((hh + 1, ww + 1), dtype=torch.int32, device=self.device)
+        self._ext.wait_stream(torch.cuda.current_stream(self.device))
+        check(self._lib.svi_brief_integral_dev(self._h, s, _p(out)), "svi_brief_integral_dev")
+        torch.cuda.current_stream(self.device).wait_stream(self._ext)
+        return out
+
+    def __call__(self, side, roi, seg, kp_uv):
+        s = 0 if side in (0, "left") else 1
+        n = roi.shape[0]
+        total_in = int(kp_uv.shape[0])
+        roi_i = roi.to(torch.int32).contiguous() if roi.dtype != torch.int32 else roi.contiguous()
+        seg = seg.contiguous()
+        kp_uv = kp_uv.contiguous()
+        seg_out = torch.empty((n + 1,), dtype=torch.int32, device=self.device)
+        kp_out = torch.empty((max(total_in, 1), 2), dtype=torch.float32, device=self.device)
+        desc = torch.empty((max(total_in, 1), 32), dtype=torch.uint8, device=self.device)
+        total = C.c_int64(0)
+        self._ext.wait_stream(torch.cuda.current_stream(self.device))
+        check(self._lib.svi_brief_compute_dev(self._h, s, _p(roi_i), _p(seg), _p(kp_uv), n, total_in, _p(seg_out), _p(kp_out), _p(desc),
+                                              C.byref(total)), "svi_brief_compute_dev")
+        torch.cuda.current_stream(self.device).wait_stream(self._ext)
+        return seg_out, kp_out[:total.value], desc[:total.value]
