@@ -157,6 +157,35 @@ def test_elimination_orders_agree(svi, tile):
     assert a[6] < b[6], (a[6], b[6])        # nested dissection: fewer launches on the critical path
 
 
+def test_loop_closure_tracks_break_the_band(svi, oracle):
+    """landmarks re-observed by key frames far away (a revisit): the reduced system is no longer banded, the order
+    search has to cope (crossing tracks only add dependencies or fall back to the natural order); oracle parity"""
+    prob = synth.make_ba_problem(90, 3000, 24000, seed=13)
+    r = np.random.default_rng(2)
+    last_seen = np.full(prob["n_lm"], -1)
+    np.maximum.at(last_seen, prob["obs_lm"], prob["obs_kf"])
+    early = np.nonzero((last_seen >= 0) & (last_seen < prob["n_kf"] - 30))[0]
+    extra_lm = r.choice(early, 60, replace=False)
+    extra_kf = (prob["n_kf"] - 1 - r.integers(0, 10, 60)).astype(np.int64)     # seen again from the last ten key frames
+    res = []
+    for cls, kw in ((svi.BundleAdjuster, dict(chol_tile=48)), (oracle.OracleBA, {})):
+        ba, _ = _make(cls, prob, **kw)
+        Rt, tt = prob["R_true"], prob["t_true"]
+        z = np.einsum("nji,nj->ni", Rt[extra_kf], prob["lm_true"][extra_lm] - tt[extra_kf])
+        info = np.tile(np.array([10.0, 0, 0, 10.0, 0, 10.0]), (60, 1))
+        ba.add_edges_bulk(np.zeros(60, np.int32), 1000000 + extra_kf, extra_lm, z, info, np.ones(60, np.int32))
+        ba.initialize()
+        n = ba.optimize(5)
+        res.append((n, ba.get_poses()[1], ba.get_landmarks()[1], ba.chi2()[0]))
+        if cls is svi.BundleAdjuster:
+            st = ba.stats()
+            assert st.chol_steps <= -(-st.chol_n // 48)
+    (ng, Tg, pg, cg), (no, To, po, co) = res
+    assert ng == no
+    assert _rel(Tg[:, 9:], To[:, 9:]) < REL and np.abs(Tg[:, :9] - To[:, :9]).max() < REL and _rel(pg, po) < REL
+    assert abs(cg - co) <= 1e-6 * co
+
+
 def test_c3_first_block_parity(svi, oracle):
     """BASELINE config 3 (100 KF / 20 k landmarks / 150 k edges): optimize(1) + optimize(10)."""
     prob = synth.make_c3()
@@ -224,6 +253,52 @@ def test_write_back_rules(svi, oracle, small):
     assert np.array_equal(ids_g, out["lm_ids"][keep]) and np.array_equal(p_g - shift, out["lm_xyz"][keep])
     g.initialize()                                           # the pruned graph optimises on
     assert g.optimize(1) == 1
+
+
+def _tiny_graph(cls, n_free, n_lm, seed, fix_all=False):
+    """hand-built graph: pose 1000000 fixed at the origin, n_free poses along +z, landmarks seen by every pose"""
+    r = np.random.default_rng(seed)
+    cam = synth.kitti_camera()
+    ba = cls(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"])
+    ident = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0.0])
+    ba.add_pose(1000000, ident, True)
+    for k in range(n_free):
+        T = ident.copy()
+        T[9:] = [0.02 * (k + 1), 0.0, 0.8 * (k + 1)]
+        ba.add_pose(1000001 + k, T + np.concatenate([np.zeros(9), r.normal(0, 0.02, 3)]), fix_all)
+    pts = np.stack([r.uniform(-3, 3, n_lm), r.uniform(-1, 1, n_lm), 0.8 * n_free + r.uniform(6, 20, n_lm)], 1)
+    for l in range(n_lm):
+        ba.add_landmark(l, pts[l] + r.normal(0, 0.05, 3))
+        for k in range(n_free + 1):
+            pc = pts[l] - np.array([0.02 * k, 0.0, 0.8 * k])
+            z = pc + r.normal(0, 0.01, 3)
+            ba.add_edges_bulk([0], [1000000 + k], [l], z[None], (1000.0 / z[2] * np.array([1, 0, 0, 1, 0, 1.0]))[None], [1])
+    return ba
+
+
+@pytest.mark.parametrize("n_free,n_lm,fix_all", [(1, 3, False), (0, 5, False), (3, 1, False), (2, 6, True), (17, 40, False)])
+def test_degenerate_and_tiny_graphs(svi, oracle, n_free, n_lm, fix_all):
+    """one free pose, no free pose at all (pure landmark refinement), a single landmark, every pose fixed, and a system
+    of exactly one tile plus one pose: same LM trajectory as the oracle"""
+    g = _tiny_graph(svi.BundleAdjuster, n_free, n_lm, 3, fix_all)
+    o = _tiny_graph(oracle.OracleBA, n_free, n_lm, 3, fix_all)
+    g.initialize()
+    o.initialize()
+    assert g.optimize(4) == o.optimize(4)
+    _, Tg = g.get_poses()
+    _, To = o.get_poses()
+    _, pg = g.get_landmarks()
+    _, po = o.get_landmarks()
+    assert np.abs(Tg - To).max() < 1e-7 and np.abs(pg - po).max() < 1e-7
+    cg, co = g.chi2(), o.chi2()
+    assert abs(cg[0] - co[0]) <= 1e-6 * max(1.0, co[0]) and abs(cg[1] - co[1]) <= 1e-6 * max(1.0, co[1])
+    # run to convergence: at the noise floor the gain ratio's sign is rounding noise, so only the block structure
+    # (nominal count) and the converged state are compared, not the number of accepted steps
+    ng, no = g.optimize_until(), o.optimize_until()
+    assert ng[0] == no[0]
+    cg, co = g.chi2(), o.chi2()
+    assert abs(cg[0] - co[0]) <= 1e-6 * max(1.0, co[0])
+    assert np.abs(g.get_landmarks()[1] - o.get_landmarks()[1]).max() < 1e-6
 
 
 def test_unsupported_shapes_fail_loudly(svi, small):
