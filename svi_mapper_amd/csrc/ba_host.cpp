@@ -594,8 +594,8 @@ int build_structure(svi_ba* ba)
     for (int i = 0; i < n_items; ++i) {
         it_pack[4 * i] = items[i].lm; it_pack[4 * i + 1] = items[i].a0; it_pack[4 * i + 2] = items[i].b0; it_pack[4 * i + 3] = items[i].masks;
     }
-    const int tdiv = getenv("SVI_SCHUR_DIV") ? atoi(getenv("SVI_SCHUR_DIV")) : 1536;
-    const int target = (int)std::min<int64_t>(1024, std::max<int64_t>(16, n_items / tdiv));
+    // ~1.6 wavefront jobs per SIMD of the chip (measured: more, shorter jobs only move work into k_assemble)
+    const int target = (int)std::min<int64_t>(1024, std::max<int64_t>(16, n_items / 1536));
     std::vector<int> job_item0(1, 0), job_sub;
     for (int i = 0; i < n_items;) {
         const int sub = items[i].sub;
