@@ -661,6 +661,42 @@ class OracleFundamentalMatcher:
                 out[i] = dict(status=e.code)
         return out
 
+    def manual(self, rec, kp_size, detector, extractor, last_l, last_r, ref_l):
+        """trackManual (:1366-2019): per landmark stage 1 LEFT/RIGHT, then stage 2 LEFT/RIGHT, then the epipolar search"""
+        s1 = self.stage1(rec, kp_size, extractor, last_l, last_r)
+        out = []
+        for i in range(len(rec)):
+            d = dict(s1[i], stage=1 if s1[i]["status"] == M_OK else 0)
+            if s1[i]["status"] not in (M_OK, M_SKIPPED):
+                one = rec[i:i + 1]
+                s2 = self.stage2(one, kp_size[i:i + 1], detector, extractor, last_l[i:i + 1], last_r[i:i + 1])[0]
+                d = dict(s2, stage=2 if s2["status"] == M_OK else 0)
+                if s2["status"] != M_OK:
+                    s3 = self.epipolar(one, kp_size[i:i + 1], extractor, last_l[i:i + 1], ref_l[i:i + 1])[0]
+                    if s3["status"] != M_SKIPPED:
+                        d = dict(s3, stage=3 if s3["status"] == M_OK else 0)
+            out.append(d)
+        return out
+
+    def new_landmarks(self, extractor, uv_left, kp_size, desc_left):
+        """addNewLandmarks (:109-175): getPointTriangulatedInRIGHTFull for every detected key point"""
+        out = []
+        prm_depth = dict(self.st)
+        for i in range(len(uv_left)):
+            kp = np.float32(kp_size[i])
+            half = np.float32(4) * kp
+            tl = np.array([max(np.float32(0), np.float32(uv_left[i][0]) - np.float32(60.0) - half), np.float32(uv_left[i][1]) - half], np.float32)
+            st = self.st
+            try:
+                self.st = dict(prm_depth, depth_min=-1.0e300, depth_max=1.0e300)
+                uvo, xyz, d_other = self._stereo(extractor, 0, kp, np.float32(0), desc_left[i], None, np.asarray(uv_left[i], np.float32), tl, -1, 0)
+                out.append(dict(status=M_OK, uv_left=np.asarray(uv_left[i], np.float32), uv_right=uvo, xyz=xyz, desc_left=desc_left[i], desc_right=d_other))
+            except NoMatch as e:
+                out.append(dict(status=e.code))
+            finally:
+                self.st = st
+        return out
+
 
 # ------------------------------------------------------------------------------------------------
 # CSolverStereoPosit (oracle_posit.c)

@@ -3,6 +3,8 @@
 Reference shapes mirrored here (src/core/CFundamentalMatcher.{h,cpp})
   getPoseStereoPosit stage 1 / stage 2        :368-733      -> FundamentalMatcher.track_stage1 / track_stage2
   trackEpipolar (stage 3)                     :794-1030     -> FundamentalMatcher.track_epipolar
+  trackManual (stages 1 -> 2 -> 3)            :1366-2019    -> FundamentalMatcher.track_manual
+  addNewLandmarks                             :109-175      -> FundamentalMatcher.add_new_landmarks
   _getMatchSampleRecursiveU/V                 :2142-2334    -> FundamentalMatcher.epipolar_samples
   _getMatch                                   :2336-2397    -> FundamentalMatcher.get_match
   _addMeasurementToLandmarkLEFT               :2400-2450    -> the stereo half of track_epipolar
@@ -386,6 +388,50 @@ class FundamentalMatcher:
                 break
             todo = todo[~found]
             depth += self.recursion_step
+        return res
+
+    # ---- trackManual (:1366-2019): stage 1 -> stage 2 -> epipolar, each only for what the previous one lost ----------
+    def track_manual(self, plan, detector, extractor, last_desc_left, last_desc_right, ref_desc_left, active=None):
+        """One StageResult; `stage` (int8: 1, 2, 3, 0 = none) tells which stage produced each measurement.  A landmark
+        outside the field of view of either camera is not tracked at all (:1415, :2008-2012)."""
+        r1 = self.track_stage1(plan, extractor, last_desc_left, last_desc_right, active)
+        tried = r1.status != MATCH_SKIPPED
+        lost1 = tried & (r1.status != MATCH_OK)
+        r2 = self.track_stage2(plan, detector, extractor, last_desc_left, last_desc_right, lost1.to(torch.uint8))
+        lost2 = lost1 & (r2.status != MATCH_OK)
+        r3 = self.track_epipolar(plan, extractor, last_desc_left, ref_desc_left, lost2.to(torch.uint8))
+        out = StageResult(plan.n, self.device)
+        out.stage = torch.zeros(plan.n, dtype=torch.int8, device=self.device)
+        out.status = torch.where(tried, r1.status, out.status)
+        for k, r in ((1, r1), (2, r2), (3, r3)):
+            ran = r.status != MATCH_SKIPPED
+            out.status = torch.where(ran, r.status, out.status)
+            good = r.status == MATCH_OK
+            for name in ("uv_left", "uv_right", "xyz_left", "desc_left", "desc_right"):
+                getattr(out, name)[good] = getattr(r, name)[good]
+            out.stage[good] = k
+        return out
+
+    # ---- addNewLandmarks (:109-175) ------------------------------------------------------------------------------------
+    def add_new_landmarks(self, extractor, uv_left, kp_size, desc_left):
+        """Stereo partner + triangulation of freshly detected key points: getPointTriangulatedInRIGHTFull with the search
+        window of CTriangulator::fMinimumSearchRangePixels = 60 (no depth gate, no second descriptor check).
+        uv_left n x 2 f32, kp_size n f32, desc_left n x 32 u8 (the detector / extractor output on the LEFT image)."""
+        n = uv_left.shape[0]
+        res = StageResult(n, self.device)
+        half = 4 * kp_size
+        topleft = torch.stack([torch.clamp_min(uv_left[:, 0] - 60.0 - half, 0.0), uv_left[:, 1] - half], 1).contiguous()   # :119-120
+        prm = self.stereo_params(0, -1, 0)
+        prm.depth_min, prm.depth_max = -1.0e300, 1.0e300
+        seg, st_range, roi, total = self.stereo_range(0, uv_left.contiguous(), topleft, kp_size.contiguous())
+        pool_uv = self.stereo_candidates(0, kp_size.contiguous(), seg, total)
+        seg2, pool_uv2, pool = extractor("right", roi, seg, pool_uv)
+        run = (st_range == MATCH_OK).to(torch.uint8)
+        idx, dist, status, uv_other, xyz = self.stereo_verify(prm, desc_left.contiguous(), None, uv_left.contiguous(), topleft, seg2, pool, pool_uv2, run)
+        status = torch.where(st_range != MATCH_OK, st_range, status)
+        won = (seg2[:-1] + idx.clamp(min=0)).long()
+        desc_other = pool[won.clamp(max=max(pool.shape[0] - 1, 0))] if pool.shape[0] else torch.zeros((n, 32), dtype=torch.uint8, device=self.device)
+        self._store(res, torch.arange(n, device=self.device), status, uv_left, uv_other, xyz, desc_left, desc_other)
         return res
 
 

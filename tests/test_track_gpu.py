@@ -261,6 +261,34 @@ def test_cascades_match_the_per_landmark_replay(oracle, cam, torch, fm):
     assert np.array_equal(res.uv_left.cpu().numpy()[ok], g["s3_uv_left"][ok])
 
 
+def test_track_manual_and_new_landmarks(oracle, cam, torch, fm):
+    """trackManual = stage 1 -> 2 -> 3 per landmark; addNewLandmarks = stereo partner of fresh key points"""
+    sc = ts.Scene(n=350, seed=17)
+    rec, seg = cpu_plan(oracle, cam, sc)
+    plan = gpu_plan(torch, fm, sc)
+    om = oracle.OracleFundamentalMatcher(cam, sc.stereo_dict())
+    ext, det = sc.make_extractor(torch, "cuda"), sc.make_detector(torch, "cuda")
+    ll, lr, rf = dev(torch, sc.last_left), dev(torch, sc.last_right), dev(torch, sc.ref_desc)
+    got = fm.track_manual(plan, det, ext, ll, lr, rf)
+    want = om.manual(rec, sc.kp_size, sc.detect_one, sc.extract_one, sc.last_left, sc.last_right, sc.ref_desc)
+    check_stage(got, want, sc.n)
+    stage = got.stage.cpu().numpy()
+    assert np.array_equal(stage, np.array([d["stage"] for d in want], np.int8))
+    assert {1, 2, 3} <= set(stage.tolist())
+    # fresh key points: the true pixels of the landmarks (where the synthetic image carries their descriptor) + distractors
+    inside = (sc.true_uL >= 80) & (sc.true_uL < ts.W - 30) & (sc.true_v >= 30) & (sc.true_v < ts.H - 30)
+    uv = np.stack([sc.true_uL[inside], sc.true_v[inside]], 1).astype(np.float32)
+    uv = np.concatenate([uv, np.array([[10, 100], [700.5, 200], [ts.W - 1, 50]], np.float32)])
+    size = np.full(len(uv), 7, np.float32)
+    desc = np.concatenate([sc.cur_left[inside], sc.describe(0, [10, 700, ts.W - 1], [100, 200, 50])])
+    got = fm.add_new_landmarks(ext, dev(torch, uv), dev(torch, size), dev(torch, desc))
+    want = om.new_landmarks(sc.extract_one, uv, size, desc)
+    st = check_stage(got, want, len(uv))
+    assert (st == 0).sum() > 50 and (st != 0).sum() > 0
+    z = got.xyz_left.cpu().numpy()[st == 0, 2]
+    assert np.all(z > 0)
+
+
 def test_large_frame_properties(torch, fm):
     """200k landmarks (far beyond a real frame): segment table is a scan of the counts, every sample lies inside its
     ROI, ragged matching of a pool against itself finds itself"""
