@@ -99,8 +99,8 @@ struct BaDev {
     int TS, NT;            // tile edge, tiles per side
     int n_tiles;           // stored tiles
     const int* tile_map;   // [NT][NT] lower triangle -> tile id or -1
-    double* S;             // red_buf: [n_tiles][TS*TS] | g[NT*TS]   (one all-reduce per trial)
-    double* g;             // = S + n_tiles*TS*TS
+    double* g;             // red_buf: g[NT*TS] | tiles with contributions | fill-in tiles; the first red_count doubles
+    double* S;             // = g + NT*TS : [n_tiles][TS*TS]                       (g + contributing tiles) are all-reduced per trial
     int     red_count;
     double* Lt;            // [n_tiles][TS*TS] Cholesky factor tiles
     double* Linv;          // [NT][TS*TS] inverses of the diagonal Cholesky factors

@@ -444,6 +444,7 @@ int build_structure(svi_ba* ba)
             if (ri >= 0 && rj >= 0) { const int a = std::max(ri, rj) / PB, b = std::min(ri, rj) / PB; nz[(size_t)a * NT + b] = 1; }
         }
     }
+    const std::vector<uint8_t> nz_orig = nz; // tiles that receive Schur / pose-edge contributions (before fill-in)
     // symbolic fill, right-looking over tile columns
     std::vector<int> h_col_ptr(NT + 1, 0);
     std::vector<std::pair<int, int>> col_rows;            // (k, i)
@@ -460,11 +461,18 @@ int build_structure(svi_ba* ba)
             }
     }
     h_col_ptr[NT] = (int)col_rows.size();
+    // tile ids: the tiles with contributions first, pure fill-in tiles after them - only the former (and g) have to
+    // cross the all-reduce, the latter are zero on every rank until the factorisation fills them
     std::vector<int> tile_map((size_t)NT * NT, -1), tile_ti, tile_tj;
-    for (int j = 0; j < NT; ++j)
-        for (int i = j; i < NT; ++i)
-            if (nz[(size_t)i * NT + j]) { tile_map[(size_t)i * NT + j] = (int)tile_ti.size(); tile_ti.push_back(i); tile_tj.push_back(j); }
+    for (int pass = 0; pass < 2; ++pass)
+        for (int j = 0; j < NT; ++j)
+            for (int i = j; i < NT; ++i)
+                if (nz[(size_t)i * NT + j] && (nz_orig[(size_t)i * NT + j] != 0) == (pass == 0)) {
+                    tile_map[(size_t)i * NT + j] = (int)tile_ti.size(); tile_ti.push_back(i); tile_tj.push_back(j);
+                }
     const int n_tiles = (int)tile_ti.size();
+    int n_tiles_orig = 0;
+    for (size_t q = 0; q < nz_orig.size(); ++q) n_tiles_orig += nz_orig[q] ? 1 : 0;
     std::vector<int> trsm_tile, trsm_row, diag_tile(NT);
     for (auto& kr : col_rows) { trsm_tile.push_back(tile_map[(size_t)kr.second * NT + kr.first]); trsm_row.push_back(kr.second); }
     for (int k = 0; k < NT; ++k) diag_tile[k] = tile_map[(size_t)k * NT + k];
@@ -689,9 +697,10 @@ int build_structure(svi_ba* ba)
     SVI_TRY(dev_alloc(ba, (size_t)4 * std::max(n_lm_blocks, 1), &d.block_part));
     d.TS = TS; d.NT = NT; d.n_tiles = n_tiles;
     SVI_TRY(dev_upload(ba, tile_map, &d.tile_map));
-    d.red_count = n_tiles * TS * TS + NT * TS;
-    SVI_TRY(dev_alloc(ba, (size_t)d.red_count, &d.S));
-    d.g = d.S + (size_t)n_tiles * TS * TS;
+    // [ g | tiles with contributions | fill-in tiles ]: the all-reduce payload is the prefix g + contributing tiles
+    d.red_count = NT * TS + n_tiles_orig * TS * TS;
+    SVI_TRY(dev_alloc(ba, (size_t)NT * TS + (size_t)n_tiles * TS * TS, &d.g));
+    d.S = d.g + (size_t)NT * TS;
     SVI_TRY(dev_alloc(ba, (size_t)n_tiles * TS * TS, &d.Lt));
     SVI_TRY(dev_alloc(ba, (size_t)NT * TS * TS, &d.Linv));
     SVI_TRY(dev_alloc(ba, (size_t)NT * TS, &d.dx));
@@ -801,7 +810,7 @@ int trial(svi_ba* ba, double lambda, bool* failed)
     t.end(s);
     t.begin(SVI_PH_ASSEMBLE, s); ba_assemble(d, s); t.end(s);
     SVI_HIP(hipGetLastError());
-    SVI_TRY(allreduce(ba, d.S, (size_t)d.red_count));
+    SVI_TRY(allreduce(ba, d.g, (size_t)d.red_count));
     t.begin(SVI_PH_CHOLESKY, s);
     if (d.NT > 0 && chol_factor_solve(ba->plan, d.S, d.Lt, d.Linv, d.g, d.dx, lambda, 6 * d.Pf, d.chol_status, s) != 0)
         return fail(SVI_ERR_HIP, "Cholesky kernels could not be configured (LDS request refused)");
@@ -1409,7 +1418,7 @@ int svi_ba_debug_reduced_system(svi_ba* ba, double lambda, double* S, double* g,
     ba_schur(d, ba->stream);
     ba_assemble(d, ba->stream);
     SVI_HIP(hipGetLastError());
-    SVI_TRY(allreduce(ba, d.S, (size_t)d.red_count));
+    SVI_TRY(allreduce(ba, d.g, (size_t)d.red_count));
     const int TS = d.TS, NT = d.NT;
     std::vector<double> tiles((size_t)d.n_tiles * TS * TS), gv((size_t)NT * TS);
     std::vector<int> tmap((size_t)NT * NT);
