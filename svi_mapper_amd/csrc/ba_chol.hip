@@ -56,6 +56,35 @@ __device__ __forceinline__ void rows_to_lds(const double* __restrict__ g, int r0
     }
 }
 
+// a whole TS x TS tile through registers: issue the global loads early, park them in LDS later (512 threads)
+template <int TS> struct TileRegs { static constexpr int N = TS * TS / 2, IT = (N + 512 - 1) / 512; double2 v[IT]; };
+
+template <int TS>
+__device__ __forceinline__ void tile_load(const double* __restrict__ g, TileRegs<TS>& t)
+{
+    const double2* src = reinterpret_cast<const double2*>(g);
+#pragma unroll
+    for (int it = 0; it < TileRegs<TS>::IT; ++it) {
+        const int i = it * 512 + threadIdx.x;
+        if (TileRegs<TS>::N % 512 == 0 || i < TileRegs<TS>::N) t.v[it] = src[i];
+    }
+}
+
+template <int TS>
+__device__ __forceinline__ void tile_store(const TileRegs<TS>& t, double* s)
+{
+    constexpr int LD = Lds<TS>::LD;
+#pragma unroll
+    for (int it = 0; it < TileRegs<TS>::IT; ++it) {
+        const int i = it * 512 + threadIdx.x;
+        if (TileRegs<TS>::N % 512 == 0 || i < TileRegs<TS>::N) {
+            const int r = i / (TS / 2), c = 2 * (i % (TS / 2));
+            s[r * LD + c] = t.v[it].x;
+            s[r * LD + c + 1] = t.v[it].y;
+        }
+    }
+}
+
 // 16x16 block of C = A B' (A: rows ra.., B: rows rb.. of LDS images with stride LD), K = KK
 template <int KK, int LD>
 __device__ __forceinline__ v4f64 mfma_block(const double* sA, int ra, const double* sB, int rb)
@@ -121,10 +150,16 @@ __device__ __forceinline__ bool potrf_sweep(const double* __restrict__ A, double
     // pending updates of this tile from the columns of the level just below: A -= L(k,q) L(k,q)' and the forward
     // substitution g_k -= L(k,q) y_q, done here so the critical path is one launch per level.  L(k,q) is staged in
     // the (still unused) L image, y_q in s_rs; both halves of the workgroup run the same barriers.
+    static_assert(kPotrfThreads == 512, "TileRegs assumes 512 threads");
+    TileRegs<TS> pre;
+    double ypre = 0.0;
+    if (npre > 0) { tile_load<TS>(Lt + (size_t)pre_tile[0] * TS * TS, pre); if (tid < TS) ypre = y[pre_col[0] * TS + tid]; }
     for (int w = 0; w < npre; ++w) {
-        rows_to_lds<TS, TS, kPotrfThreads>(Lt + (size_t)pre_tile[w] * TS * TS, 0, sL);
-        if (tid < TS) s_rs[tid] = y[pre_col[w] * TS + tid];
+        tile_store<TS>(pre, sL);
+        if (tid < TS) s_rs[tid] = ypre;
         __syncthreads();
+        // the next source tile travels while this one is applied
+        if (w + 1 < npre) { tile_load<TS>(Lt + (size_t)pre_tile[w + 1] * TS * TS, pre); if (tid < TS) ypre = y[pre_col[w + 1] * TS + tid]; }
         for (int m = 0; m < TS; m += 2) {
             double2 rr[NI > 0 ? NI : 1], cc[NB];
 #pragma unroll
