@@ -676,11 +676,25 @@ __global__ __launch_bounds__(kBlock) void k_assemble(BaDev d)
     const int cx = d.sub_cx[sub], cy = d.sub_cy[sub], n = 6 * d.Pf, TS = d.TS;
     const int j0 = d.sub_job_ptr[sub], j1 = d.sub_job_ptr[sub + 1];
     // slabs: element e = q*64 + lane  ->  block (i,j) = (lane>>3, lane&7), entry (rr,cc) = (q/6, q%6)
-    for (int e = tid; e < 36 * 64; e += kBlock) {
-        double v = 0.0;
-        for (int jb = j0; jb < j1; ++jb) v -= d.slab[(size_t)jb * 36 * 64 + e];
-        const int q = e >> 6, lane = e & 63;
-        s_t[(lane >> 3) * 6 + q / 6][(lane & 7) * 6 + q % 6] = v;
+    {
+        // 9 elements per thread, all in flight for every job (the jobs are still summed in ascending order)
+        constexpr int NE = 36 * 64 / kBlock;
+        double v[NE];
+#pragma unroll
+        for (int u = 0; u < NE; ++u) v[u] = 0.0;
+        for (int jb = j0; jb < j1; ++jb) {
+            const double* sl = d.slab + (size_t)jb * 36 * 64 + tid;
+            double w[NE];
+#pragma unroll
+            for (int u = 0; u < NE; ++u) w[u] = sl[u * kBlock];
+#pragma unroll
+            for (int u = 0; u < NE; ++u) v[u] -= w[u];
+        }
+#pragma unroll
+        for (int u = 0; u < NE; ++u) {
+            const int e = u * kBlock + tid, q = e >> 6, lane = e & 63;
+            s_t[(lane >> 3) * 6 + q / 6][(lane & 7) * 6 + q % 6] = v[u];
+        }
     }
     __syncthreads();
     if (d.add_pose_terms) {
