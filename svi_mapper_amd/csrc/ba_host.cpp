@@ -236,7 +236,8 @@ int build_structure(svi_ba* ba)
             int best_depth = 0, best_tiles = 0;
             analyse(best, best_depth, best_tiles);
             const int wmax = std::max(1, (span + PBo - 1) / PBo);
-            for (int w = 1; w <= wmax && w <= 8; ++w) {
+            // (the symbolic analysis is cubic in the tile count: very long sequences only try the span-wide separator)
+            for (int w = (NTo > 256 ? std::min(wmax, 8) : 1); w <= wmax && w <= 8; ++w) {
                 if (!make_perm(w, cand)) break;
                 int dp = 0, tl = 0;
                 analyse(cand, dp, tl);
