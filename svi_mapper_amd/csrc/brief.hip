@@ -52,16 +52,43 @@ __global__ __launch_bounds__(256) void k_integral_rows(const uint8_t* __restrict
     }
 }
 
-__global__ __launch_bounds__(256) void k_integral_cols(int w, int h, int32_t* __restrict__ sum)
+constexpr int kColSegs = 8; // row segments of the column pass, one wavefront each
+
+__global__ __launch_bounds__(64 * kColSegs) void k_integral_cols(int w, int h, int32_t* __restrict__ sum)
 {
-    const int x = blockIdx.x * blockDim.x + threadIdx.x;
-    if (x > w) return;
+    // workgroup = 64 columns; wavefront s owns the rows of segment s: running sums inside the segment first, then the
+    // totals of the segments above are added (two short dependent chains instead of one of length h)
+    __shared__ int32_t s_tot[kColSegs][64];
+    const int lane = threadIdx.x & 63, seg = threadIdx.x >> 6;
+    const int x = blockIdx.x * 64 + lane;
+    const int rows = (h + kColSegs - 1) / kColSegs;
+    const int y0 = 1 + seg * rows, y1 = min(y0 + rows, h + 1);
+    const size_t W = (size_t)w + 1;
     int32_t run = 0;
-    sum[x] = 0;
-    for (int y = 1; y <= h; ++y) {
-        run += sum[(size_t)y * (w + 1) + x];
-        sum[(size_t)y * (w + 1) + x] = run;
+    if (x <= w) {
+        if (seg == 0) sum[x] = 0;
+        for (int yb = y0; yb < y1; yb += 16) { // 16 rows in flight: loads first, then the running sums, then the stores
+            int32_t v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = (yb + u < y1) ? sum[(size_t)(yb + u) * W + x] : 0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) { run += v[u]; v[u] = run; }
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (yb + u < y1) sum[(size_t)(yb + u) * W + x] = v[u];
+        }
     }
+    s_tot[seg][lane] = run;
+    __syncthreads();
+    int32_t off = 0;
+    for (int q = 0; q < seg; ++q) off += s_tot[q][lane];
+    if (x <= w && off != 0)
+        for (int yb = y0; yb < y1; yb += 16) {
+            int32_t v[16];
+#pragma unroll
+            for (int u = 0; u < 16; ++u) v[u] = (yb + u < y1) ? sum[(size_t)(yb + u) * W + x] : 0;
+#pragma unroll
+            for (int u = 0; u < 16; ++u) if (yb + u < y1) sum[(size_t)(yb + u) * W + x] = v[u] + off;
+        }
 }
 
 __device__ __forceinline__ bool roi_ok(const int4 r, int w, int h)
@@ -223,7 +250,7 @@ int svi_brief_set_image_dev(svi_brief* b, int side, const uint8_t* image, int wi
     }
     b->w[side] = width; b->h[side] = height;
     hipLaunchKernelGGL(k_integral_rows, dim3((height + 3) / 4), dim3(256), 0, st, image, width, height, stride, b->sum[side]);
-    hipLaunchKernelGGL(k_integral_cols, dim3((width + 1 + 255) / 256), dim3(256), 0, st, width, height, b->sum[side]);
+    hipLaunchKernelGGL(k_integral_cols, dim3((width + 1 + 63) / 64), dim3(64 * kColSegs), 0, st, width, height, b->sum[side]);
     SVI_HIP(hipGetLastError());
     return SVI_OK;
 }
