@@ -10,8 +10,8 @@
 //   k_brief_count                       wavefront per ROI: key points that survive the border filter
 //   k_scan_i32 (tracker.hip twin)       segment starts of the compacted pools
 //   k_brief_compact                     wavefront per ROI: stable compaction (ballot + popcount ranks)
-//   k_brief_describe                    wavefront per kept key point: lane = 4 tests (8 box sums, 32 integral reads,
-//                                       all inside a 57x57 neighbourhood: L1/L2 hits), bits gathered with shuffles
+//   k_brief_describe                    wavefront per kept key point: its 58x58 window of the integral image staged in LDS
+//                                       (coalesced rows), lane = 4 tests (8 box sums, 32 LDS reads), bits gathered with shuffles
 // Integer work, latency / cache bound (a frame: ~66 k key points x 2048 integral reads).
 #include <hip/hip_runtime.h>
 
@@ -168,30 +168,46 @@ __global__ __launch_bounds__(256) void k_brief_compact(const int4* __restrict__ 
     }
 }
 
-__device__ __forceinline__ int32_t box9(const int32_t* __restrict__ sum, int w, int h, int cx, int cy)
-{
-    const size_t W = (size_t)w + 1;
-    const int x0 = min(max(cx - 4, 0), w), x1 = min(max(cx + 5, 0), w), y0 = min(max(cy - 4, 0), h), y1 = min(max(cy + 5, 0), h);
-    return sum[(size_t)y1 * W + x1] - sum[(size_t)y1 * W + x0] - sum[(size_t)y0 * W + x1] + sum[(size_t)y0 * W + x0];
-}
+constexpr int kPatch = 58; // integral samples around a key point: offsets -28 .. +29 (24 + 4 and 24 + 5)
 
 __global__ __launch_bounds__(256) void k_brief_describe(const int32_t* __restrict__ sum, int w, int h, const int8_t* __restrict__ pattern,
                                                         const int4* __restrict__ roi, const float2* __restrict__ kp_out,
                                                         const int32_t* __restrict__ owner, const int32_t* __restrict__ total,
                                                         uint32_t* __restrict__ desc)
 {
-    const int j = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // one wavefront per key point: its 58 x 58 window of the integral image is staged in LDS with coalesced row loads
+    // (coordinates clamped to the frame), then every lane evaluates 4 tests = 8 box sums = 32 LDS reads
+    __shared__ int32_t s_patch[4][kPatch * kPatch];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int j = blockIdx.x * 4 + wave;
     if (j >= *total) return;
     const int4 r = roi[owner[j]];
     const float2 p = kp_out[j];
     const int cx = r.x + static_cast<int>(static_cast<double>(p.x) + 0.5), cy = r.y + static_cast<int>(static_cast<double>(p.y) + 0.5);
-    // lane handles tests 4*lane .. 4*lane+3 = half of descriptor byte lane/2
+    int32_t* patch = s_patch[wave];
+    const size_t W = (size_t)w + 1;
+    if (lane < kPatch) {
+        const int gx = min(max(cx - 28 + lane, 0), w);
+        // all 58 row loads of the lane are issued before the first one is parked (one round trip, not 58)
+        int32_t v[kPatch];
+#pragma unroll
+        for (int yy = 0; yy < kPatch; ++yy) v[yy] = sum[(size_t)min(max(cy - 28 + yy, 0), h) * W + gx];
+#pragma unroll
+        for (int yy = 0; yy < kPatch; ++yy) patch[yy * kPatch + lane] = v[yy];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    // box centred at offset (ox, oy): corners at patch[(28 + oy + {5,-4})][(28 + ox + {5,-4})]
+    auto box = [&](int oy, int ox) {
+        const int x0 = 24 + ox, x1 = 33 + ox, y0 = (24 + oy) * kPatch, y1 = (33 + oy) * kPatch;
+        return patch[y1 + x1] - patch[y1 + x0] - patch[y0 + x1] + patch[y0 + x0];
+    };
     uint32_t bits = 0;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const char4 t = reinterpret_cast<const char4*>(pattern)[4 * lane + q];
-        const int32_t a = box9(sum, w, h, cx + t.y, cy + t.x);
-        const int32_t b = box9(sum, w, h, cx + t.w, cy + t.z);
+        const int32_t a = box(t.x, t.y);
+        const int32_t b = box(t.z, t.w);
         const int tt = 4 * lane + q;
         if (a < b) bits |= 1u << (7 - (tt & 7));
     }
