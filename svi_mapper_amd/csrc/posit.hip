@@ -48,9 +48,8 @@ __device__ void quat_R(double w, double x, double y, double z, double* R)
 }
 
 // Eigen::LDLT: lower Cholesky with diagonal pivoting; x holds the right-hand side, then the solution
-__device__ void ldlt_solve6(double* A, double* x)
+__device__ void ldlt_solve6(double* A, double* x, int* perm)
 {
-    int perm[6];
     for (int k = 0; k < 6; ++k) {
         int p = k;
         double big = fabs(A[7 * k]);
@@ -82,6 +81,8 @@ __global__ __launch_bounds__(kThreads) void k_stereo_posit(PositArgs a)
 {
     __shared__ double s_T[12];
     __shared__ double s_red[kThreads / 64][kAcc];
+    __shared__ double s_H[36], s_dx[6];   // the 6x6 system of thread 0 (dynamic indexing: LDS, not scratch)
+    __shared__ int    s_perm[6];
     __shared__ int    s_m, s_stop;
     __shared__ double s_prev;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -171,14 +172,16 @@ __global__ __launch_bounds__(kThreads) void k_stereo_posit(PositArgs a)
         }
         __syncthreads();
         if (tid == 0) {
-            double H[36], dx[6], sum[kAcc];
+            double* H = s_H;
+            double* dx = s_dx;
+            double* sum = s_red[0]; // wave sums folded into row 0 in ascending wave order
             for (int k = 0; k < kAcc; ++k) { double v = s_red[0][k]; for (int w = 1; w < kThreads / 64; ++w) v += s_red[w][k]; sum[k] = v; }
             int q = 0;
             for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { H[6 * r + c] = sum[q]; H[6 * c + r] = sum[q]; ++q; }
             for (int k = 0; k < 6; ++k) dx[k] = -sum[21 + k];
             const double total = sum[27];
             const int inliers = static_cast<int>(sum[28]);
-            ldlt_solve6(H, dx);                                                                   // :109
+            ldlt_solve6(H, dx, s_perm);                                                           // :109
             double dR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
             const double w2 = dx[3] * dx[3] + dx[4] * dx[4] + dx[5] * dx[5];
             if (1.0 > w2) quat_R(sqrt(1.0 - w2), dx[3], dx[4], dx[5], dR);
