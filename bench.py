@@ -35,7 +35,7 @@ FP64_MFMA_PEAK_TF = 78.6   # SURVEY.md §8d (FP64 vector/matrix)
 def cached_problem(scale):
     """config 4 (x landmark scale), cached under /tmp because the numpy generator takes ~40 s."""
     from svi_mapper_amd import synth
-    path = "/tmp/svi_c4_scale%d_v2.npz" % scale
+    path = "/tmp/svi_c4_scale%d_v3.npz" % scale
     keys = ("R_true", "t_true", "R_init", "t_init", "lm_true", "lm_init", "obs_kf", "obs_lm", "uvL", "uvR", "xyz")
     if os.path.exists(path):
         try:
@@ -249,6 +249,11 @@ def main():
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
     torch.cuda.set_device(local)
+    if world > 1:
+        # rank 0 generates (and caches) the synthetic graph, the others pick the cache up afterwards
+        if rank == 0:
+            cached_problem(world)
+        dist.barrier()
     prob = cached_problem(world)
     cam = prob["cam"]
 

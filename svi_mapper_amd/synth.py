@@ -121,7 +121,7 @@ def trajectory(n_kf, step=1.0, straight=40, turn=15):
 
 
 def make_ba_problem(n_kf=100, n_lm=20000, n_edges=150000, seed=0xC3, px_sigma=0.5,
-                    pose_sigma_t=0.05, pose_sigma_r_deg=0.5, max_run=40):
+                    pose_sigma_t=0.05, pose_sigma_r_deg=0.5, max_run=40, pose_init=None):
     """Raw synthetic problem (numpy). Keys:
       cam, R_true,t_true, R_init,t_init (LEFT->WORLD), lm_true, lm_init,
       obs_kf, obs_lm (sorted by keyframe), uvL, uvR (float32), xyz (f64, getPointInLEFT of the pixels)"""
@@ -192,6 +192,8 @@ def make_ba_problem(n_kf=100, n_lm=20000, n_edges=150000, seed=0xC3, px_sigma=0.
     dt[0] = 0
     R_init = R @ _small_rot(w)
     t_init = t + dt
+    if pose_init is not None:   # another landmark set of the SAME (perturbed) trajectory: make_c4(landmark_scale > 1)
+        R_init, t_init = pose_init
 
     # Size the problem on the number of edges the reference's admission rule will keep
     # (Cg2oOptimizer.cpp:1402-1452, replicated here only to count): trim runs from either end,
@@ -203,13 +205,16 @@ def make_ba_problem(n_kf=100, n_lm=20000, n_edges=150000, seed=0xC3, px_sigma=0.
     uvL, uvR, xyz = measure(full_lm, full_kf, rng)
     l2abs = (xyz ** 2).sum(1)
     disp_ok = (uvL[:, 0] - uvR[:, 0]) > 1.0
+    # (the per-observation quantities are kept up to date incrementally: a trimming step only touches the
+    # observations of the landmarks it trimmed - same values as recomputing everything, a tenth of the time)
+    keep = (full_kf >= kstart[full_lm]) & (full_kf < (kstart + run)[full_lm])
+    first = off0 + (kstart - kstart0)
+    lm_init = np.einsum("nij,nj->ni", R_init[kstart], xyz[first]) + t_init[kstart]
+    pe = np.einsum("nji,nj->ni", R_init[full_kf], lm_init[full_lm] - t_init[full_kf])
+    rel = (pe ** 2).sum(1) / l2abs
+    type_ok = (l2abs < 50.0) | ((l2abs < 10000.0) & disp_ok)
     for _ in range(400):
-        keep = (full_kf >= kstart[full_lm]) & (full_kf < (kstart + run)[full_lm])
-        first = off0 + (kstart - kstart0)
-        lm_init = np.einsum("nij,nj->ni", R_init[kstart], xyz[first]) + t_init[kstart]
-        pe = np.einsum("nji,nj->ni", R_init[full_kf], lm_init[full_lm] - t_init[full_kf])
-        rel = (pe ** 2).sum(1) / l2abs
-        adm = keep & (rel > 0.75) & (rel < 1.25) & ((l2abs < 50.0) | ((l2abs < 10000.0) & disp_ok))
+        adm = keep & (rel > 0.75) & (rel < 1.25) & type_ok
         excess = int(adm.sum()) - n_edges
         if excess <= max(8, n_edges // 2000):
             break
@@ -221,6 +226,19 @@ def make_ba_problem(n_kf=100, n_lm=20000, n_edges=150000, seed=0xC3, px_sigma=0.
         head = rng.random(len(sel)) < 0.5
         kstart[sel[head]] += 1
         run[sel] -= 1
+        # observations of the trimmed landmarks
+        cnt = run0[sel]
+        idx = np.repeat(off0[sel], cnt) + (np.arange(int(cnt.sum())) - np.repeat(np.cumsum(cnt) - cnt, cnt))
+        il, ik = full_lm[idx], full_kf[idx]
+        keep[idx] = (ik >= kstart[il]) & (ik < (kstart + run)[il])
+        hs = sel[head]                      # their first observation moved: the initial position changes
+        if len(hs):
+            fh = off0[hs] + (kstart[hs] - kstart0[hs])
+            lm_init[hs] = np.einsum("nij,nj->ni", R_init[kstart[hs]], xyz[fh]) + t_init[kstart[hs]]
+            ch = run0[hs]
+            ih = np.repeat(off0[hs], ch) + (np.arange(int(ch.sum())) - np.repeat(np.cumsum(ch) - ch, ch))
+            peh = np.einsum("nji,nj->ni", R_init[full_kf[ih]], lm_init[full_lm[ih]] - t_init[full_kf[ih]])
+            rel[ih] = (peh ** 2).sum(1) / l2abs[ih]
     obs_lm, obs_kf = full_lm[keep], full_kf[keep]
     uvL, uvR, xyz = uvL[keep], uvR[keep], xyz[keep]
 
@@ -234,9 +252,35 @@ def make_c3(seed=0xC3):
     return make_ba_problem(100, 20000, 150000, seed)
 
 
+def _c4_part(args):
+    seed, pose_init = args
+    return make_ba_problem(500, 100000, 800000, seed, pose_init=pose_init)
+
+
 def make_c4(seed=0xC4, landmark_scale=1):
-    """landmark_scale > 1 grows the landmark/edge count at fixed keyframes (weak scaling shards)."""
-    return make_ba_problem(500, 100000 * landmark_scale, 800000 * landmark_scale, seed)
+    """BASELINE config 4.  landmark_scale s > 1 (weak-scaling shards): s landmark sets of 100 k / 800 k edges each over
+    the same 500 key frames and the same perturbed initial poses - set 0 is config 4 itself, sets 1.. are further
+    draws (seed + 7919 c), generated in parallel processes."""
+    base = make_ba_problem(500, 100000, 800000, seed)
+    if landmark_scale <= 1:
+        return base
+    jobs = [(seed + 7919 * c, (base["R_init"], base["t_init"])) for c in range(1, landmark_scale)]
+    try:
+        import multiprocessing as mp
+        with mp.get_context("fork").Pool(min(len(jobs), 8)) as pool:
+            parts = [base] + pool.map(_c4_part, jobs)
+    except Exception:
+        parts = [base] + [_c4_part(j) for j in jobs]
+    n_lm = base["n_lm"]
+    obs_kf = np.concatenate([q["obs_kf"] for q in parts])
+    order = np.argsort(obs_kf, kind="stable")
+    cat = lambda k: np.concatenate([q[k] for q in parts])[order]  # noqa: E731
+    out = dict(base)
+    out.update(n_lm=n_lm * len(parts), lm_true=np.concatenate([q["lm_true"] for q in parts]),
+               lm_init=np.concatenate([q["lm_init"] for q in parts]), obs_kf=obs_kf[order],
+               obs_lm=np.concatenate([q["obs_lm"] + c * n_lm for c, q in enumerate(parts)])[order],
+               uvL=cat("uvL"), uvR=cat("uvR"), xyz=cat("xyz"))
+    return out
 
 
 def pose12(R, t):
