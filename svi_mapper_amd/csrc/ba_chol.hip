@@ -186,7 +186,6 @@ __device__ __forceinline__ bool potrf_sweep(const double* __restrict__ A, double
     bool fail = false;
 #pragma unroll
     for (int jb = 0; jb < NB; ++jb) {
-        constexpr int dummy = 0; (void)dummy;
         // first owned block row with a >= jb
         const int i0 = (jb <= H) ? 0 : (jb - H + 1) / 2;
         for (int jq = 0; jq < 16 / KB; ++jq) {
