@@ -107,8 +107,13 @@ def test_lm_schedule_invariants(oracle):
     assert (tr[:, 1] <= tr[:, 0] * (1 + 1e-12)).all()          # accepted steps never increase the robust chi2
     assert (tr[1:, 0] == tr[:-1, 1]).all()                      # chi2 carries over between iterations
     # lambda is re-initialised at the start of every optimize() block (iterations 0, 1, 11, 21, ...)
+    # inside a block an iteration accepted at its first trial scales lambda by a factor in [1/3, 2/3]
     lam_after = tr[:, 2]
-    assert lam_after[1] > lam_after[0] or tr[1, 3] > 1 or True
+    starts = {0} | set(range(1, len(tr), 10))
+    inner = [i for i in range(1, len(tr)) if i not in starts and tr[i, 3] == 1]
+    assert len(inner) > 0
+    ratio = lam_after[inner] / lam_after[[i - 1 for i in inner]]
+    assert (ratio > 1 / 3 - 1e-12).all() and (ratio < 2 / 3 + 1e-12).all()
     p1, r1 = ba.chi2()
     assert r1 < r0 and p1 < p0
     # the gravity edges contribute exactly 1.0 each to both sums
