@@ -13,7 +13,7 @@ pytestmark = pytest.mark.gpu
 def torch():
     import torch
     if not torch.cuda.is_available():
-        pytest.skip("no GPU")
+        pytest.fail("the -m gpu tests need a visible GPU (torch.cuda.is_available() is False)")
     return torch
 
 

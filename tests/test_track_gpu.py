@@ -16,7 +16,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 def torch():
     import torch
     if not torch.cuda.is_available():
-        pytest.skip("no GPU")
+        pytest.fail("the -m gpu tests need a visible GPU (torch.cuda.is_available() is False)")
     return torch
 
 
