@@ -30,6 +30,7 @@ void ba_linearize_pose(const BaDev& d, int cur, void* st);
 void ba_linearize_aux(const BaDev& d, int cur, int rank, void* st);
 void ba_chi2_aux(const BaDev& d, int which, int rank, void* st);
 void ba_pose_finalize(const BaDev& d, const int* red_slot, int rank, int n_ranks, void* st);
+void ba_publish(const BaDev& d, int n, double* h_scal, int* h_status, int seq, void* st);
 void ba_lin_post(const BaDev& d, int n_ranks, void* st);
 void ba_invert_landmarks(const BaDev& d, double lambda, void* st);
 void ba_schur(const BaDev& d, void* st);
@@ -749,6 +750,8 @@ int build_structure(svi_ba* ba)
 
     SVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&ba->h_scal), 16 * sizeof(double)));
     SVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&ba->h_status), sizeof(int) * 4));
+    ba->h_status[0] = ba->h_status[1] = 0;
+    ba->pub_seq = 0;
     ba_configure_kernels(TS);
     SVI_HIP(hipStreamSynchronize(ba->stream));
 
@@ -771,15 +774,33 @@ int build_structure(svi_ba* ba)
 // ---------------------------------------------------------------------------------------------
 int read_scalars(svi_ba* ba, int n)
 {
-    SVI_HIP(hipMemcpyAsync(ba->h_scal, ba->d.scal, sizeof(double) * n, hipMemcpyDeviceToHost, ba->stream));
-    SVI_HIP(hipMemcpyAsync(ba->h_status, ba->d.chol_status, sizeof(int), hipMemcpyDeviceToHost, ba->stream));
-    SVI_HIP(hipStreamSynchronize(ba->stream));
-    ba->timer.collect();
+    if (ba->timer.on) { // profiling: a full stream synchronisation, the phase events are collected behind it
+        SVI_HIP(hipMemcpyAsync(ba->h_scal, ba->d.scal, sizeof(double) * n, hipMemcpyDeviceToHost, ba->stream));
+        SVI_HIP(hipMemcpyAsync(ba->h_status, ba->d.chol_status, sizeof(int), hipMemcpyDeviceToHost, ba->stream));
+        SVI_HIP(hipStreamSynchronize(ba->stream));
+        ba->timer.collect();
+        return SVI_OK;
+    }
+    // One LM decision per trial hangs on these few numbers: a kernel stores them into pinned host memory and the host
+    // spins on the sequence number - no copy-engine launches, no interrupt wake-up (tens of microseconds each way).
+    const int seq = ++ba->pub_seq;
+    ba_publish(ba->d, n, ba->h_scal, ba->h_status, seq, ba->stream);
+    SVI_HIP(hipGetLastError());
+    volatile int* flag = ba->h_status + 1;
+    for (long spin = 0;; ++spin) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
+        if ((spin & 0xFFF) == 0xFFF) { // every few thousand polls: has the stream died or drained without publishing?
+            const hipError_t q = hipStreamQuery(ba->stream);
+            if (q == hipSuccess) { if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break; SVI_HIP(hipStreamSynchronize(ba->stream)); if (*flag == seq) break; return fail(SVI_ERR_HIP, "result publication lost"); }
+            if (q != hipErrorNotReady) return fail(SVI_ERR_HIP, "stream failed while waiting for the trial results: %s", hipGetErrorString(q));
+        }
+        __builtin_ia32_pause();
+    }
     return SVI_OK;
 }
 
 // computeActiveErrors + buildSystem at state `cur`; leaves chi2 (robust, plain) and max|H_jj| in h_scal[0,1,5]
-int linearize(svi_ba* ba)
+int linearize(svi_ba* ba, bool read = true)
 {
     BaDev& d = ba->d;
     hipStream_t s = ba->stream;
@@ -794,7 +815,7 @@ int linearize(svi_ba* ba)
     SVI_TRY(allreduce(ba, d.lin_buf, (size_t)d.lin_count));
     ba_lin_post(d, ba->opt.n_ranks, s);
     SVI_HIP(hipGetLastError());
-    return read_scalars(ba, 8);
+    return read ? read_scalars(ba, 8) : SVI_OK; // unread: the numbers wait in scal[8..10] for the next read
 }
 
 // one trial: solve (H + lambda I) dx = b through the Schur complement, apply, evaluate.
@@ -826,7 +847,7 @@ int trial(svi_ba* ba, double lambda, bool* failed)
     t.end(s);
     SVI_HIP(hipGetLastError());
     SVI_TRY(allreduce(ba, d.scal, 3));
-    SVI_TRY(read_scalars(ba, 8));
+    SVI_TRY(read_scalars(ba, 12));
     *failed = ba->h_status[0] != 0;
     return SVI_OK;
 }
@@ -864,16 +885,29 @@ int optimize_block(svi_ba* ba, int iterations, int* performed)
     const svi_ba_options& o = ba->opt;
     int done = 0;
     for (int it = 0; it < iterations; ++it) {
-        SVI_TRY(linearize(ba));
-        double chi = ba->h_scal[0];
-        ba->last_robust = chi; ba->last_plain = ba->h_scal[1]; ba->have_chi = true;
-        if (it == 0) { ba->lambda = o.lm_tau * ba->h_scal[5]; ba->ni = 2.0; } // computeLambdaInit, per optimize() call
+        // Only the first iteration of a block needs the linearisation results on the host before the trial can be
+        // launched (lambda_0 = tau * max H_jj); afterwards lambda is known and the host reads chi2 of the linearisation
+        // together with the results of the first trial - one host round trip per iteration instead of two.
+        const bool read_now = it == 0 || ba->timer.on;
+        SVI_TRY(linearize(ba, read_now));
+        double chi = 0.0;
+        bool have_lin = read_now;
+        if (read_now) {
+            chi = ba->h_scal[0];
+            ba->last_robust = chi; ba->last_plain = ba->h_scal[1]; ba->have_chi = true;
+            if (it == 0) { ba->lambda = o.lm_tau * ba->h_scal[5]; ba->ni = 2.0; } // computeLambdaInit, per optimize() call
+        }
         double rho = 0.0;
         int q = 0;
         bool stop_inf = false;
         do {
             bool failed = false;
             SVI_TRY(trial(ba, ba->lambda, &failed));
+            if (!have_lin) {
+                chi = ba->h_scal[8];
+                ba->last_robust = chi; ba->last_plain = ba->h_scal[9]; ba->have_chi = true;
+                have_lin = true;
+            }
             double temp = ba->h_scal[0];
             if (failed) { temp = DBL_MAX; ba->stats.chol_failures++; }
             else { ba->last_robust = ba->h_scal[0]; ba->last_plain = ba->h_scal[1]; }

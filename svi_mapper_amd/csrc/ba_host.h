@@ -54,7 +54,8 @@ struct svi_ba {
     int cur = 0;
     std::vector<void*> allocs;      // everything hipMalloc'ed by initialize()
     double* h_scal = nullptr;       // pinned readback (16 doubles)
-    int*    h_status = nullptr;     // pinned
+    int*    h_status = nullptr;     // pinned: [0] factorisation status, [1] sequence number of the last published results
+    int     pub_seq = 0;
     int*    red_slot = nullptr;     // device [Pf]
     int*    e_orig = nullptr;       // device [E] lm-major edge -> insertion index
     double* lm_all = nullptr;       // device [3 * Ltot] gather buffer (multi-rank)

@@ -475,7 +475,12 @@ __global__ __launch_bounds__(kBlock) void k_lin_post(BaDev d, int n_ranks)
     }
     for (int k = threadIdx.x; k < n_ranks; k += kBlock) mx = fmax(mx, d.lin_scal[2 + k]);
     mx = block_max(mx, s_red);
-    if (threadIdx.x == 0) { d.scal[5] = mx; d.scal[0] = d.lin_scal[0]; d.scal[1] = d.lin_scal[1]; }
+    // slots 8..10 carry the same numbers and survive the trial kernels (which rewrite 0..3): the host may pick them up
+    // together with the trial results instead of waiting here
+    if (threadIdx.x == 0) {
+        d.scal[5] = mx; d.scal[0] = d.lin_scal[0]; d.scal[1] = d.lin_scal[1];
+        d.scal[8] = d.lin_scal[0]; d.scal[9] = d.lin_scal[1]; d.scal[10] = mx;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -923,6 +928,23 @@ void ba_linearize_pose(const BaDev& d, int cur, void* st)
     if (d.info_planes == 3) hipLaunchKernelGGL(k_linearize_pose<true>, dim3(d.n_chunks), dim3(kBlock), 0, S_(st), d, cur);
     else hipLaunchKernelGGL(k_linearize_pose<false>, dim3(d.n_chunks), dim3(kBlock), 0, S_(st), d, cur);
 }
+// Results for the host without a copy engine round trip: the scalars go straight into pinned host memory, the
+// sequence number last (system-scope release); the host spins on the sequence number (ba_host.cpp read_scalars).
+__global__ __launch_bounds__(64) void k_publish(const double* __restrict__ scal, int n, const int* __restrict__ status, double* h_scal,
+                                                int* h_status, int seq)
+{
+    if ((int)threadIdx.x < n) __hip_atomic_store(h_scal + threadIdx.x, scal[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) __hip_atomic_store(h_status, *status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(h_status + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+void ba_publish(const BaDev& d, int n, double* h_scal, int* h_status, int seq, void* st)
+{
+    hipLaunchKernelGGL(k_publish, dim3(1), dim3(64), 0, S_(st), d.scal, n, d.chol_status, h_scal, h_status, seq);
+}
+
 void ba_linearize_aux(const BaDev& d, int cur, int, void* st)
 {
     hipLaunchKernelGGL((k_aux_edges<true>), dim3(d.aux_blocks), dim3(kAuxThreads), 0, S_(st), d, cur);
