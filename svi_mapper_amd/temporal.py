@@ -118,6 +118,7 @@ class FundamentalMatcher:
         self.device = torch.device("cuda", device)
         # the library launches on the matcher's own stream: order torch's work on the current stream around it
         self._ext = torch.cuda.ExternalStream(self.matcher.stream, device=self.device)
+        self._dummy = torch.zeros(64, dtype=torch.uint8, device=self.device)
 
     # ------------------------------------------------------------------------------------------
     def _enter(self):
@@ -128,6 +129,13 @@ class FundamentalMatcher:
 
     def _empty(self, shape, dtype):
         return torch.empty(shape, dtype=dtype, device=self.device)
+
+    def _q(self, t):
+        """device pointer of a pool-like tensor; an EMPTY tensor has a null data_ptr in torch, the C ABI wants an address
+        (it reads nothing from it: the segment table says the pools are empty)"""
+        if t is None:
+            return None
+        return t.data_ptr() if t.numel() else self._dummy.data_ptr()
 
     # ---- plan ----------------------------------------------------------------------------------
     def plan(self, T_world_to_left, dp_T_left_to_world, motion_scaling, xyz_world, kp_size, last_disparity, uv_reference, dp_index):
@@ -165,7 +173,7 @@ class FundamentalMatcher:
         roi = self._empty((n_sel, 4), torch.float32)
         self._enter()
         check(self._lib.svi_track_epipolar_samples_dev(self._h, C.byref(self._cam), _p(plan.records), _p(plan.kp_size), _p(sel), n_sel, _p(seg),
-                                                       int(depth), _p(sample_uv), _p(roi)), "svi_track_epipolar_samples_dev")
+                                                       int(depth), self._q(sample_uv), self._q(roi)), "svi_track_epipolar_samples_dev")
         self._leave()
         return seg, sample_uv, roi
 
@@ -177,7 +185,7 @@ class FundamentalMatcher:
         dist = self._empty((nq,), torch.int32)
         status = self._empty((nq,), torch.int32)
         self._enter()
-        check(self._lib.svi_match_ragged_dev(self._h, _p(ref), _p(original), _p(active), nq, _p(seg), _p(pool), int(cutoff),
+        check(self._lib.svi_match_ragged_dev(self._h, _p(ref), _p(original), _p(active), nq, _p(seg), self._q(pool), int(cutoff),
                                              int(cutoff_original if cutoff_original is not None else 257), _p(idx), _p(dist), _p(status)),
               "svi_match_ragged_dev")
         self._leave()
@@ -190,8 +198,8 @@ class FundamentalMatcher:
         topleft = self._empty((n_sel, 2), torch.float32)
         ok = self._empty((n_sel,), torch.uint8)
         self._enter()
-        check(self._lib.svi_track_handover_dev(self._h, int(mode), _p(plan.records), _p(plan.kp_size), _p(sel), n_sel, _p(seg), _p(pool_uv),
-                                               _p(idx), _p(roi), _p(uv_ref), _p(topleft), _p(ok)), "svi_track_handover_dev")
+        check(self._lib.svi_track_handover_dev(self._h, int(mode), _p(plan.records), _p(plan.kp_size), _p(sel), n_sel, _p(seg), self._q(pool_uv),
+                                               _p(idx), self._q(roi), _p(uv_ref), _p(topleft), _p(ok)), "svi_track_handover_dev")
         self._leave()
         return uv_ref, topleft, ok
 
@@ -211,7 +219,7 @@ class FundamentalMatcher:
     def stereo_candidates(self, search_in_left, kp_size, seg, total):
         pool_uv = self._empty((total, 2), torch.float32)
         self._enter()
-        check(self._lib.svi_track_stereo_candidates_dev(self._h, int(search_in_left), _p(kp_size), kp_size.shape[0], _p(seg), _p(pool_uv)),
+        check(self._lib.svi_track_stereo_candidates_dev(self._h, int(search_in_left), _p(kp_size), kp_size.shape[0], _p(seg), self._q(pool_uv)),
               "svi_track_stereo_candidates_dev")
         self._leave()
         return pool_uv
@@ -230,7 +238,7 @@ class FundamentalMatcher:
         xyz = self._empty((nq, 3), torch.float64)
         self._enter()
         check(self._lib.svi_track_stereo_verify_dev(self._h, C.byref(params), _p(ref), _p(last_other), _p(active), _p(uv_ref), _p(topleft), nq,
-                                                    _p(seg), _p(pool), _p(pool_uv), _p(idx), _p(dist), _p(status), _p(uv_other), _p(xyz)),
+                                                    _p(seg), self._q(pool), self._q(pool_uv), _p(idx), _p(dist), _p(status), _p(uv_other), _p(xyz)),
               "svi_track_stereo_verify_dev")
         self._leave()
         return idx, dist, status, uv_other, xyz

@@ -289,6 +289,25 @@ def test_track_manual_and_new_landmarks(oracle, cam, torch, fm):
     assert np.all(z > 0)
 
 
+def test_nothing_to_track(oracle, cam, torch, fm):
+    """every landmark inactive / no landmark at all: the cascades run through with empty pools"""
+    sc = ts.Scene(n=64, seed=4)
+    plan = gpu_plan(torch, fm, sc)
+    ext, det = sc.make_extractor(torch, "cuda"), sc.make_detector(torch, "cuda")
+    ll, lr, rf = dev(torch, sc.last_left), dev(torch, sc.last_right), dev(torch, sc.ref_desc)
+    off = torch.zeros(sc.n, dtype=torch.uint8, device="cuda")
+    for res in (fm.track_stage1(plan, ext, ll, lr, off), fm.track_stage2(plan, det, ext, ll, lr, off), fm.track_epipolar(plan, ext, ll, rf, off),
+                fm.track_manual(plan, det, ext, ll, lr, rf, off)):
+        assert (res.status == 8).all()
+    # landmarks that match nothing (random descriptors): the stereo stage gets no work at all
+    junk = dev(torch, np.random.default_rng(0).integers(0, 256, (sc.n, 32), dtype=np.uint8))
+    res = fm.track_epipolar(plan, ext, junk, junk)
+    assert (res.status != 0).all()
+    e = lambda *shape, dt=torch.float32: torch.zeros(shape, dtype=dt, device="cuda")  # noqa: E731
+    res = fm.add_new_landmarks(ext, e(0, 2), e(0), e(0, 32, dt=torch.uint8))
+    assert res.status.numel() == 0
+
+
 def test_large_frame_properties(torch, fm):
     """200k landmarks (far beyond a real frame): segment table is a scan of the counts, every sample lies inside its
     ROI, ragged matching of a pool against itself finds itself"""

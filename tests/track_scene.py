@@ -205,3 +205,57 @@ class Scene:
     def stereo_dict(self):
         duf = -DUR
         return dict(f=FX, cx=CX, cy=CY, duR_flipped=duf, min_disparity=0.01, depth_min=duf / W, depth_max=duf / 0.01, width=W)
+
+
+class Sequence:
+    """A short drive past a fixed landmark cloud: frame(t) is a Scene-like object (same synthetic-image interface) for
+    the true pose of frame t, with per-frame appearance noise on the landmark descriptors."""
+
+    def __init__(self, n=400, n_frames=8, seed=3, step=0.7):
+        r = np.random.default_rng(seed)
+        self.n, self.n_frames = n, n_frames
+        self.T_l2w = [pack(rot(0.001 * t, 0.006 * t, -0.0005 * t), [0.015 * t, -0.002 * t, step * t]) for t in range(n_frames)]
+        # landmarks in front of frame 0, deep enough to stay visible for a while
+        z = np.exp(r.uniform(np.log(6.0), np.log(60.0), n)) + step * n_frames * 0.5
+        u, v = r.uniform(60, W - 60, n), r.uniform(50, H - 50, n)
+        self.xyz_world = np.stack([(u - CX) / FX * z, (v - CY) / FX * z, z], 1)
+        self.base_desc = r.integers(0, 256, (n, 32), dtype=np.uint8)
+        self.kp_size = np.full(n, 7.0, np.float32)
+        self._r = r
+
+    def frame(self, t):
+        f = Scene.__new__(Scene)
+        f.n, f.motion_scaling = self.n, 1.0
+        T = inv12(self.T_l2w[t])
+        f.T_true_w2l = T
+        pc = self.xyz_world @ T[:9].reshape(3, 3).T + T[9:]
+        zt = np.maximum(pc[:, 2], 0.5)
+        f.true_uL = np.rint(FX * pc[:, 0] / zt + CX).astype(np.int64)
+        f.true_v = np.rint(FX * pc[:, 1] / zt + CY).astype(np.int64)
+        disp = np.maximum(np.rint(-DUR / zt), 1).astype(np.int64)
+        f.true_uR = f.true_uL - disp
+        f.true_disparity = disp.astype(np.float32)
+        f.cur_left = np.stack([flip_bits(self.base_desc[i], 3 + (7 * t + i) % 5, 10000 * t + i) for i in range(self.n)])
+        f.cur_right = np.stack([flip_bits(f.cur_left[i], (3 * t + i) % 6, 20000 * t + i) for i in range(self.n)])
+        f.feat = [np.full((H, W), -1, np.int32), np.full((H, W), -1, np.int32)]
+        f.fdist = [np.zeros((H, W), np.int32), np.zeros((H, W), np.int32)]
+        for i in range(self.n):
+            if pc[i, 2] <= 1.0:
+                continue
+            for side, uu in ((0, f.true_uL[i]), (1, f.true_uR[i])):
+                for dy in range(-2, 3):
+                    for dx in range(-2, 3):
+                        x, y = uu + dx, f.true_v[i] + dy
+                        if 0 <= x < W and 0 <= y < H:
+                            f.feat[side][y, x] = i
+                            f.fdist[side][y, x] = max(abs(dx), abs(dy))
+        rr = np.random.default_rng(500 + t)
+        f.corners = []
+        for side in (0, 1):
+            uu = f.true_uL if side == 0 else f.true_uR
+            ok = (uu >= 0) & (uu < W) & (f.true_v >= 0) & (f.true_v < H) & (pc[:, 2] > 1.0)
+            pts = np.stack([uu[ok], f.true_v[ok]], 1)
+            extra = np.stack([rr.integers(0, W, 800), rr.integers(0, H, 800)], 1)
+            allp = np.unique(np.concatenate([pts, extra]), axis=0)
+            f.corners.append(allp[np.lexsort((allp[:, 0], allp[:, 1]))].astype(np.float32))
+        return f
