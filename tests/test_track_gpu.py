@@ -289,6 +289,28 @@ def test_track_manual_and_new_landmarks(oracle, cam, torch, fm):
     assert np.all(z > 0)
 
 
+def test_many_random_frames(oracle, cam, torch, fm):
+    """24 further random frames (different motion scalings, pose errors, key point sizes): plan, both sampling depths and the
+    stage-3 cascade stay bit-identical"""
+    for seed in range(100, 124):
+        r = np.random.default_rng(seed)
+        sc = ts.Scene(n=int(r.integers(50, 400)), seed=seed, pose_error=float(r.uniform(0, 0.05)),
+                      kp_sizes=(7.0, float(r.choice([7.0, 5.5, 9.25]))), motion_scaling=float(r.uniform(0.2, 3.0)))
+        rec, seg = cpu_plan(oracle, cam, sc)
+        plan = gpu_plan(torch, fm, sc)
+        assert np.array_equal(plan.records.cpu().numpy(), rec.view(np.uint8).reshape(len(rec), -1)), seed
+        assert np.array_equal(plan.seg.cpu().numpy(), seg), seed
+        for depth in (0, 2):
+            want, want_roi = oracle.track_epipolar_samples(cam, rec, sc.kp_size, seg, depth)
+            _, got, got_roi = fm.epipolar_samples(plan, depth)
+            assert np.array_equal(raw(got.cpu().numpy()), raw(want)) and np.array_equal(raw(got_roi.cpu().numpy()), raw(want_roi)), (seed, depth)
+        if seed % 4 == 0:
+            om = oracle.OracleFundamentalMatcher(cam, sc.stereo_dict())
+            ext = sc.make_extractor(torch, "cuda")
+            check_stage(fm.track_epipolar(plan, ext, dev(torch, sc.last_left), dev(torch, sc.ref_desc)),
+                        om.epipolar(rec, sc.kp_size, sc.extract_one, sc.last_left, sc.ref_desc), sc.n)
+
+
 def test_nothing_to_track(oracle, cam, torch, fm):
     """every landmark inactive / no landmark at all: the cascades run through with empty pools"""
     sc = ts.Scene(n=64, seed=4)
