@@ -157,6 +157,28 @@ def test_elimination_orders_agree(svi, tile):
     assert a[6] < b[6], (a[6], b[6])        # nested dissection: fewer launches on the critical path
 
 
+@pytest.mark.parametrize("seed", [21, 22, 23, 24, 25, 26])
+def test_random_problems(svi, oracle, seed):
+    """further random graphs of different shapes, both tile sizes and elimination orders: same LM trajectory as the oracle"""
+    r = np.random.default_rng(seed)
+    n_kf = int(r.integers(8, 70))
+    n_lm = int(r.integers(200, 3000))
+    prob = synth.make_ba_problem(n_kf, n_lm, int(n_lm * r.uniform(4, 8)), seed=seed)
+    g, sg = _make(svi.BundleAdjuster, prob, chol_tile=int(r.choice([48, 96])), chol_order=int(r.integers(0, 2)))
+    o, so = _make(oracle.OracleBA, prob)
+    np.testing.assert_array_equal(sg, so)
+    g.initialize()
+    o.initialize()
+    for n in (1, 7):
+        assert g.optimize(n) == o.optimize(n)
+    _, Tg = g.get_poses()
+    _, To = o.get_poses()
+    _, pg = g.get_landmarks()
+    _, po = o.get_landmarks()
+    assert _rel(Tg[:, 9:], To[:, 9:]) < REL and np.abs(Tg[:, :9] - To[:, :9]).max() < REL and _rel(pg, po) < REL
+    assert abs(g.last_plain_chi2 - o.last_plain_chi2) <= 1e-6 * o.last_plain_chi2
+
+
 def test_loop_closure_tracks_break_the_band(svi, oracle):
     """landmarks re-observed by key frames far away (a revisit): the reduced system is no longer banded, the order
     search has to cope (crossing tracks only add dependencies or fall back to the natural order); oracle parity"""
