@@ -179,6 +179,39 @@ def test_random_problems(svi, oracle, seed):
     assert abs(g.last_plain_chi2 - o.last_plain_chi2) <= 1e-6 * o.last_plain_chi2
 
 
+def test_full_information_matrices(svi, oracle):
+    """edges with non-diagonal information (a .g2o graph may carry them; the reference itself only sets diagonals): the
+    six-plane kernels instead of the diagonal specialisation"""
+    prob = synth.make_ba_problem(14, 400, 2600, seed=31)
+    r = np.random.default_rng(9)
+    res = []
+    for cls in (svi.BundleAdjuster, oracle.OracleBA):
+        ba, _ = _make(cls, prob)
+        k = 150
+        lm = r.permutation(prob["n_lm"])[:k] if cls is svi.BundleAdjuster else lm
+        kf = (r.integers(1, prob["n_kf"], k)).astype(np.int64) if cls is svi.BundleAdjuster else kf
+        # avoid duplicating an existing (pose, landmark) edge: use landmarks ids offset into fresh landmarks
+        new_ids = 500000 + np.arange(k)
+        if cls is svi.BundleAdjuster:
+            P = prob["lm_true"][lm] + r.normal(0, 0.05, (k, 3))
+            A = r.normal(0, 1, (k, 3, 3))
+            O = np.einsum("nij,nkj->nik", A, A) + 5 * np.eye(3)
+            info = np.stack([O[:, 0, 0], O[:, 0, 1], O[:, 0, 2], O[:, 1, 1], O[:, 1, 2], O[:, 2, 2]], 1)
+            z = np.einsum("nji,nj->ni", prob["R_true"][kf], prob["lm_true"][lm] - prob["t_true"][kf]) + r.normal(0, 0.01, (k, 3))
+            kf2 = np.maximum(kf - 1, 0)
+            z2 = np.einsum("nji,nj->ni", prob["R_true"][kf2], prob["lm_true"][lm] - prob["t_true"][kf2]) + r.normal(0, 0.01, (k, 3))
+        ba.add_landmarks(new_ids, P)
+        ba.add_edges_bulk(np.zeros(k, np.int32), 1000000 + kf, new_ids, z, info, np.ones(k, np.int32))
+        ba.add_edges_bulk(np.zeros(k, np.int32), 1000000 + kf2, new_ids, z2, info, np.zeros(k, np.int32))
+        ba.initialize()
+        n = ba.optimize(5)
+        res.append((n, ba.get_poses()[1], ba.get_landmarks()[1], ba.chi2()))
+    (ng, Tg, pg, cg), (no, To, po, co) = res
+    assert ng == no
+    assert _rel(Tg[:, 9:], To[:, 9:]) < REL and np.abs(Tg[:, :9] - To[:, :9]).max() < REL and _rel(pg, po) < REL
+    assert abs(cg[0] - co[0]) <= 1e-6 * co[0] and abs(cg[1] - co[1]) <= 1e-6 * co[1]
+
+
 def test_loop_closure_tracks_break_the_band(svi, oracle):
     """landmarks re-observed by key frames far away (a revisit): the reduced system is no longer banded, the order
     search has to cope (crossing tracks only add dependencies or fall back to the natural order); oracle parity"""
