@@ -248,6 +248,7 @@ def main():
     rank, world, local = sdist.init_from_env(args.backend)
     if world != args.gpus:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (args.gpus, world, args.gpus))
+    local = local % max(torch.cuda.device_count(), 1)   # more ranks than GPUs only happens in the gloo rehearsal on one card
     torch.cuda.set_device(local)
     if world > 1:
         # rank 0 generates (and caches) the synthetic graph, the others pick the cache up afterwards
@@ -281,7 +282,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.backend == "gloo" else "cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     s1 = ba.stats()

@@ -46,6 +46,15 @@ def make_allreduce_hook(group=None):
             t = torch.as_tensor(_DevPtr(ptr, count), device=torch.device("cuda", torch.cuda.current_device()))
             cache[key] = t
         ext = torch.cuda.ExternalStream(stream)
+        if dist.get_backend(group) == "gloo":
+            # rehearsal path (several ranks sharing one GPU, or no RCCL): through the host, synchronously
+            ext.synchronize()
+            host = t.cpu()
+            dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+            with torch.cuda.stream(ext):
+                t.copy_(host)
+            ext.synchronize()
+            return 0
         with torch.cuda.stream(ext):
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
         return 0
