@@ -100,7 +100,13 @@ def bench_matcher(svi, steps=1000, warmup=50):
         return ms, float(batch) * nq * nt / (ms * 1e-3)
 
     ms, rate = timed(1, True, steps, warmup)
-    out["gated_single"] = {"ms_per_call": ms, "pairs_per_s": rate}
+    # pairs that actually pass the epipolar gate (same row, u window): the candidates the reference would have enumerated
+    g = c2["gate"]
+    tv, tu = g["t_uv"][:, 1], g["t_uv"][:, 0]
+    cand = 0
+    for i in range(nq):
+        cand += int(((np.abs(tv - g["q_uv"][i, 1]) <= g.get("v_tol", 0.0)) & (tu >= g["q_umin"][i]) & (tu < g["q_umax"][i])).sum())
+    out["gated_single"] = {"ms_per_call": ms, "pairs_per_s": rate, "gated_candidates": cand, "gated_candidates_per_s": cand / (ms * 1e-3)}
     ms, rate = timed(64, True, max(steps // 10, 20), 5)
     out["gated_batch64"] = {"ms_per_call": ms, "pairs_per_s": rate}
     ms, rate = timed(1, False, steps, warmup)
