@@ -199,6 +199,81 @@ __global__ __launch_bounds__(WAVES * 64) void k_match_hamming256(MatchArgs a)
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Row-bucketed variant for the gated single-frame call (small pool, few candidates per query): the gate keeps
+// |t.v - q.v| <= v_tol, so instead of evaluating the predicate for all NQ x NT pairs every workgroup first sorts the
+// pool by image row in LDS (counting sort on floor(v); rows outside [0, kRows) share an overflow bucket), stages the
+// descriptors, and each query lane then visits only the buckets its row window touches.  Same results as the full
+// scan: the exact predicate is re-checked per candidate and the minimum is taken on the packed (distance, index) key.
+// ---------------------------------------------------------------------------------------------
+constexpr int kRows = 512, kBucketPool = 3072, kBucketThreads = 512; // 3072 x 44 B = 132 KiB of the 160 KiB LDS
+
+__global__ __launch_bounds__(kBucketThreads) void k_match_rowbucket(MatchArgs a)
+{
+    extern __shared__ __align__(16) unsigned char smem[];
+    uint4*  s_desc = reinterpret_cast<uint4*>(smem);                         // [nt][2]
+    float2* s_uv   = reinterpret_cast<float2*>(s_desc + 2 * (size_t)a.nt);  // [nt]
+    int*    s_list = reinterpret_cast<int*>(s_uv + a.nt);                   // [nt] pool indices grouped by bucket
+    __shared__ int s_cnt[kRows + 2], s_start[kRows + 2];
+    const int tid = threadIdx.x;
+    const size_t tbase = static_cast<size_t>(blockIdx.z) * a.nt, qbase = static_cast<size_t>(blockIdx.z) * a.nq;
+    for (int b = tid; b < kRows + 2; b += kBucketThreads) s_cnt[b] = 0;
+    __syncthreads();
+    auto bucket_of = [](float v) { return (v >= 0.0f && v < static_cast<float>(kRows)) ? static_cast<int>(v) : kRows; };
+    for (int j = tid; j < a.nt; j += kBucketThreads) {
+        const float2 uv = a.t_uv[tbase + j];
+        s_uv[j] = uv;
+        s_desc[2 * j] = a.t[2 * (tbase + j)];
+        s_desc[2 * j + 1] = a.t[2 * (tbase + j) + 1];
+        atomicAdd(&s_cnt[bucket_of(uv.y)], 1);
+    }
+    __syncthreads();
+    if (tid < 64) { // exclusive scan of the 513 counts by one wavefront
+        int carry = 0;
+        for (int base = 0; base < kRows + 1; base += 64) {
+            const int b = base + tid;
+            const int v = b < kRows + 1 ? s_cnt[b] : 0;
+            int inc = v;
+            for (int off = 1; off < 64; off <<= 1) { const int o = __shfl_up(inc, off); if (tid >= off) inc += o; }
+            if (b < kRows + 1) s_start[b] = carry + inc - v;
+            carry += __shfl(inc, 63);
+        }
+        if (tid == 0) s_start[kRows + 1] = carry;
+    }
+    __syncthreads();
+    for (int b = tid; b < kRows + 1; b += kBucketThreads) s_cnt[b] = s_start[b]; // running insert positions
+    __syncthreads();
+    for (int j = tid; j < a.nt; j += kBucketThreads) s_list[atomicAdd(&s_cnt[bucket_of(s_uv[j].y)], 1)] = j;
+    __syncthreads();
+
+    for (int qi = blockIdx.x * kBucketThreads + tid; qi < a.nq; qi += gridDim.x * kBucketThreads) {
+        const size_t qglob = qbase + qi;
+        const uint4 q0 = a.q[2 * qglob], q1 = a.q[2 * qglob + 1];
+        const float2 quv = a.q_uv[qglob];
+        const float umin = a.q_umin[qglob], umax = a.q_umax[qglob];
+        unsigned long long key = kNoKey;
+        auto scan = [&](int b) {
+            for (int p = s_start[b]; p < s_start[b + 1]; ++p) {
+                const int j = s_list[p];
+                const float2 tuv = s_uv[j];
+                if ((fabsf(tuv.y - quv.y) <= a.v_tol) && (umin <= tuv.x) && (tuv.x < umax)) {
+                    const unsigned long long k = (static_cast<unsigned long long>(hamming256(q0, q1, s_desc[2 * j], s_desc[2 * j + 1])) << 32) |
+                                                 static_cast<uint32_t>(j);
+                    key = k < key ? k : key;
+                }
+            }
+        };
+        // buckets floor(qv - tol) .. floor(qv + tol), clamped; a non-finite window falls back to every bucket
+        const float lo = quv.y - a.v_tol, hi = quv.y + a.v_tol;
+        int b0 = 0, b1 = kRows - 1;
+        if (lo >= 0.0f) b0 = lo < static_cast<float>(kRows) ? static_cast<int>(lo) : kRows;
+        if (hi < static_cast<float>(kRows)) b1 = hi >= 0.0f ? static_cast<int>(hi) : -1;
+        for (int b = b0; b <= b1; ++b) scan(b);
+        scan(kRows); // rows outside the table
+        write_result(a, qglob, tbase, key, quv.x, quv.y);
+    }
+}
+
 // second pass when the pool was split across blocks
 __global__ __launch_bounds__(256) void k_match_finalize(MatchArgs a, int batch)
 {
@@ -303,6 +378,23 @@ static int launch_match(svi_matcher* m, const uint8_t* q, int nq, const uint8_t*
     a.nq = nq; a.nt = nt; a.cutoff = cutoff; a.t_seg = t_seg;
     a.out_idx = out_idx; a.out_dist = out_dist;
     if (fuse) { a.finv = 1.0 / f; a.cx = cx; a.cy = cy; a.dur = dur; a.min_disp = min_disp; a.out_xyz = out_xyz; a.out_ok = out_ok; }
+
+    // Gated call on a small pool: sort the pool by row in LDS and visit only the rows a query can match.
+    if (gate && !t_seg && nt > 0 && nt <= kBucketPool && gate->v_tol >= 0.0f && gate->v_tol <= 8.0f) {
+        const size_t lds = (size_t)nt * (32 + 8 + 4);
+        static bool attr = false;
+        if (!attr) {
+            if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_match_rowbucket), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    kBucketPool * (32 + 8 + 4)) != hipSuccess)
+                return svi::fail(SVI_ERR_HIP, "row-bucket matcher: LDS request refused");
+            attr = true;
+        }
+        a.keys = nullptr;
+        const int gx = std::max(1, std::min((nq + kBucketThreads - 1) / kBucketThreads, 8));
+        hipLaunchKernelGGL(k_match_rowbucket, dim3(gx, 1, batch), dim3(kBucketThreads), lds, m->stream, a);
+        SVI_HIP(hipGetLastError());
+        return SVI_OK;
+    }
 
     // Decomposition. Blocks = query groups x pool splits x frame pairs. Few query groups (a single
     // frame pair): use 16-wave blocks so a CU still holds 4 waves per SIMD, and split the pool over

@@ -179,6 +179,32 @@ def test_loop_closure_clouds(matcher, oracle, n_clouds, nq, max_pool):
     assert hits > 0 or n_clouds == 1
 
 
+@pytest.mark.parametrize("nq,nt,v_tol,seed", [(300, 900, 0.0, 1), (64, 3072, 1.5, 2), (1000, 50, 0.25, 3), (7, 3073, 0.0, 4), (200, 400, 9.0, 5)])
+def test_row_bucketed_gate(matcher, oracle, nq, nt, v_tol, seed):
+    """the LDS row-bucket path (small gated pools) and its fall-backs: fractional rows, rows outside the bucket table
+    (negative, >= 512, NaN), row tolerances, pools just beyond the LDS limit, tolerances beyond the bucket path"""
+    rng = np.random.default_rng(seed)
+    q, t = _rand_desc(rng, nq), _rand_desc(rng, nt)
+    t_uv = np.stack([rng.uniform(0, 1241, nt), rng.uniform(-20, 700, nt)], 1).astype(np.float32)
+    t_uv[: nt // 3, 1] = np.rint(t_uv[: nt // 3, 1])
+    t_uv[rng.integers(0, nt, 3), 1] = np.nan
+    q_uv = np.stack([rng.uniform(0, 1241, nq), rng.uniform(-5, 600, nq)], 1).astype(np.float32)
+    own = rng.integers(0, nt, nq)                      # most queries sit on the row of some pool entry
+    q_uv[:, 1] = np.where(rng.random(nq) < 0.8, t_uv[own, 1] + rng.uniform(-v_tol, v_tol, nq).astype(np.float32), q_uv[:, 1])
+    q_uv[0, 1] = np.nan
+    gate = dict(q_uv=q_uv, t_uv=t_uv, q_umin=(q_uv[:, 0] - 300).astype(np.float32), q_umax=(q_uv[:, 0] + 300).astype(np.float32), v_tol=v_tol)
+    for k in rng.integers(0, nq, 20):                  # near duplicates and exact ties inside the window
+        j = own[k]
+        t[j] = q[k]
+        t[(j + 1) % nt] = q[k]
+        t_uv[(j + 1) % nt] = t_uv[j]
+    idx, dist = matcher.match_arrays(q, t, gate, 100)
+    ridx, rdist = oracle.match_hamming256(q, t, gate, 100)
+    np.testing.assert_array_equal(idx, ridx)
+    np.testing.assert_array_equal(dist, rdist)
+    assert (ridx >= 0).sum() >= 1
+
+
 def test_split_pool_path(matcher, oracle):
     """Few queries, large ungated pool: the pool is split over workgroups and merged by atomicMin."""
     rng = np.random.default_rng(21)
