@@ -8,6 +8,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# a fresh checkout has no built library yet (built artefacts are not tracked): same step as __graft_entry__.build(),
+# done here because several test modules import the package - which loads the library - at collection time
+if not os.path.exists(os.path.join(ROOT, "svi_mapper_amd", "lib", "libsvi_hot.so")):
+    import subprocess
+    subprocess.check_call(["make", "-s", "-j4", "-C", os.path.join(ROOT, "svi_mapper_amd", "csrc")])
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
