@@ -179,6 +179,56 @@ def test_random_problems(svi, oracle, seed):
     assert abs(g.last_plain_chi2 - o.last_plain_chi2) <= 1e-6 * o.last_plain_chi2
 
 
+def _nonlinear_graph(cls, tau, rot, seed=3, n_free=6, n_lm=80):
+    """non-robust inverse-depth edges, badly rotated initial poses and (with a tiny tau) almost no damping: Gauss-Newton
+    steps that overshoot"""
+    cam = synth.kitti_camera()
+    r = np.random.default_rng(seed)
+    ba = cls(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"], lm_tau=tau)
+    ident = np.array([1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0.0])
+    ba.add_pose(1000000, ident, True)
+
+    def rotm(w):
+        th = np.linalg.norm(w)
+        k = w / th
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+    t_true = [np.array([0.05 * (k + 1), 0, 0.8 * (k + 1)]) for k in range(n_free)]
+    for k in range(n_free):
+        ba.add_pose(1000001 + k, np.concatenate([rotm(r.normal(0, rot, 3)).ravel(), t_true[k] + r.normal(0, 1.0, 3)]), False)
+    pts = np.stack([r.uniform(-4, 4, n_lm), r.uniform(-1.5, 1.5, n_lm), 0.8 * n_free + r.uniform(4, 25, n_lm)], 1)
+    for l in range(n_lm):
+        ba.add_landmark(l, pts[l] + r.normal(0, 0.5, 3))
+        for k in range(n_free + 1):
+            pc = pts[l] - (np.zeros(3) if k == 0 else t_true[k - 1])
+            z = np.array([cam["fx"] * pc[0] / pc[2] + cam["cx"], cam["fy"] * pc[1] / pc[2] + cam["cy"], 1.0 / pc[2]])
+            ba.add_edges_bulk([2], [1000000 + k], [l], z[None], np.array([[1.0, 0, 0, 1.0, 0, 1000.0]]), [0])
+    return ba
+
+
+@pytest.mark.parametrize("rot,seed", [(0.3, 3), (0.3, 9), (0.25, 1), (0.35, 6), (0.35, 8)])
+def test_rejected_trials_follow_g2o(svi, oracle, rot, seed):
+    """trials are rejected (lambda *= nu, nu *= 2, state restored) before one is accepted: the accept / reject sequence,
+    the damping and the iteration counts follow the oracle. The comparison stops while chi2 is still far above the rounding
+    floor (there the sign of rho is noise on both sides), and the undamped Gauss-Newton steps amplify the last-bit
+    differences of the two summation orders, hence 1e-4 on lambda instead of the usual 1e-6."""
+    g = _nonlinear_graph(svi.BundleAdjuster, 1e-12, rot, seed=seed)
+    o = _nonlinear_graph(oracle.OracleBA, 1e-12, rot, seed=seed)
+    g.initialize()
+    o.initialize()
+    for n in (1, 3, 3):
+        assert g.optimize(n) == o.optimize(n)
+        st = g.stats()
+        assert st.lm_trials == o.trials and st.lm_iterations == o.iterations
+        assert abs(g.lm_lambda - o.lm_lambda) <= 1e-4 * o.lm_lambda
+    assert st.lm_trials > st.lm_iterations, "the graph was supposed to provoke rejected trials"
+    cg, co = g.chi2(), o.chi2()
+    assert abs(cg[0] - co[0]) <= 1e-4 * co[0]
+    pg, po = g.get_poses()[1], o.get_poses()[1]
+    assert np.abs(pg - po).max() <= 1e-4 * np.abs(po).max()  # north_star's relative bound (translations are ~100 m)
+
+
 def test_full_information_matrices(svi, oracle):
     """edges with non-diagonal information (a .g2o graph may carry them; the reference itself only sets diagonals): the
     six-plane kernels instead of the diagonal specialisation"""
