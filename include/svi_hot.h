@@ -568,6 +568,8 @@ int svi_ba_debug_reduced_system(svi_ba* ba, double lambda, double* S, double* g,
 /* mean duration (ms) of the Jacobian sweep kernel over `reps` back-to-back launches on the handle's stream,
  * bracketed by two HIP events (the state is not modified: the sweep only writes linearisation outputs) */
 int svi_ba_debug_time_sweep(svi_ba* ba, int reps, double* ms_avg);
+/* the same for one of the two kernels of the sweep: which = 1 landmark-major (K2), 2 pose-major (K3) */
+int svi_ba_debug_time_sweep_part(svi_ba* ba, int reps, int which, double* ms_avg);
 
 /* timing probe of the diagonal-tile Cholesky kernel (tile 48 or 96): mean ms per launch over `reps`
  * launches, truncated after phase `stop_after` (0 full, 1 pivot sweep, 2 +scale/store, 3 +diagonal

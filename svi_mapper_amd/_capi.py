@@ -173,6 +173,7 @@ SIGNATURES = {
     "svi_ba_debug_reduced_system": (C.c_int, [vp, C.c_double, f64p, f64p, C.c_int64, i64p]),
     "svi_debug_chol_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, f64p]),
     "svi_ba_debug_time_sweep": (C.c_int, [vp, C.c_int, f64p]),
+    "svi_ba_debug_time_sweep_part": (C.c_int, [vp, C.c_int, C.c_int, f64p]),
 }
 
 _lib = None

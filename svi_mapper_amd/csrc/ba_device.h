@@ -93,7 +93,7 @@ struct BaDev {
     double* bp;       // = lin_buf + 21*Pf
     double* lin_scal; // = lin_buf + 27*Pf : [0] robust chi2, [1] plain chi2, [2..2+n_ranks) max diag of H_ll per rank
     int     lin_count;
-    double* block_part; // [max(n_lm_blocks, n_chunks)][4] per-workgroup partial sums
+    double* block_part; // [n_lm_blocks][4 waves][4] per-wave partial sums of the landmark-major kernels
 
     // reduced system
     int TS, NT;            // tile edge, tiles per side

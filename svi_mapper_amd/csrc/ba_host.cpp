@@ -696,7 +696,7 @@ int build_structure(svi_ba* ba)
     d.lin_count = 27 * Pf + 2 + o.n_ranks;
     SVI_TRY(dev_alloc(ba, (size_t)d.lin_count, &d.lin_buf));
     d.Hpp = d.lin_buf; d.bp = d.lin_buf + (size_t)21 * Pf; d.lin_scal = d.lin_buf + (size_t)27 * Pf;
-    SVI_TRY(dev_alloc(ba, (size_t)4 * std::max(n_lm_blocks, 1), &d.block_part));
+    SVI_TRY(dev_alloc(ba, (size_t)16 * std::max(n_lm_blocks, 1), &d.block_part));
     d.TS = TS; d.NT = NT; d.n_tiles = n_tiles;
     SVI_TRY(dev_upload(ba, tile_map, &d.tile_map));
     // [ g | tiles with contributions | fill-in tiles ]: the all-reduce payload is the prefix g + contributing tiles
@@ -1415,7 +1415,8 @@ int svi_debug_chol_probe(int device, int tile, int reps, int stop_after, double*
 }
 
 // mean duration of the Jacobian sweep (K2 + K3): `reps` back-to-back sweeps on the handle's stream between two HIP events
-int svi_ba_debug_time_sweep(svi_ba* ba, int reps, double* ms_avg)
+// which: 0 = the whole sweep (K2 then K3, back to back), 1 = K2 alone, 2 = K3 alone
+static int time_sweep_impl(svi_ba* ba, int reps, int which, double* ms_avg)
 {
     if (!ba || !ms_avg || reps < 1) return fail(SVI_ERR_INVALID, "bad argument");
     if (!ba->initialized) return fail(SVI_ERR_STATE, "debug tap before svi_ba_initialize");
@@ -1423,9 +1424,13 @@ int svi_ba_debug_time_sweep(svi_ba* ba, int reps, double* ms_avg)
     hipEvent_t a, b;
     SVI_HIP(hipEventCreate(&a));
     SVI_HIP(hipEventCreate(&b));
-    for (int i = 0; i < 3; ++i) { ba_linearize_lm(ba->d, ba->cur, ba->stream); ba_linearize_pose(ba->d, ba->cur, ba->stream); }
+    auto once = [&]() {
+        if (which != 2) ba_linearize_lm(ba->d, ba->cur, ba->stream);
+        if (which != 1) ba_linearize_pose(ba->d, ba->cur, ba->stream);
+    };
+    for (int i = 0; i < 3; ++i) once();
     SVI_HIP(hipEventRecord(a, ba->stream));
-    for (int i = 0; i < reps; ++i) { ba_linearize_lm(ba->d, ba->cur, ba->stream); ba_linearize_pose(ba->d, ba->cur, ba->stream); }
+    for (int i = 0; i < reps; ++i) once();
     SVI_HIP(hipEventRecord(b, ba->stream));
     SVI_HIP(hipEventSynchronize(b));
     float ms = 0.f;
@@ -1434,6 +1439,12 @@ int svi_ba_debug_time_sweep(svi_ba* ba, int reps, double* ms_avg)
     (void)hipEventDestroy(b);
     *ms_avg = (double)ms / reps;
     return SVI_OK;
+}
+int svi_ba_debug_time_sweep(svi_ba* ba, int reps, double* ms_avg) { return time_sweep_impl(ba, reps, 0, ms_avg); }
+int svi_ba_debug_time_sweep_part(svi_ba* ba, int reps, int which, double* ms_avg)
+{
+    if (which != 1 && which != 2) return fail(SVI_ERR_INVALID, "which must be 1 (K2) or 2 (K3)");
+    return time_sweep_impl(ba, reps, which, ms_avg);
 }
 
 // linearise at the current estimate, reduce with damping lambda, return dense S (with lambda on its

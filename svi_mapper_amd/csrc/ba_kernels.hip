@@ -56,6 +56,43 @@ __device__ __forceinline__ double block_max(double x, double* s_red /* [4] */)
     return r;
 }
 
+// sum over the 16 lanes of a DPP row (every lane of the row gets the same bits): rotate-and-add butterfly
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov(double x)
+{
+    int lo = __double2loint(x), hi = __double2hiint(x);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, 0xf, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double row16_sum(double x)
+{
+    x += dpp_mov<0x128>(x); // row_ror:8
+    x += dpp_mov<0x124>(x); // row_ror:4
+    x += dpp_mov<0x122>(x); // row_ror:2
+    x += dpp_mov<0x121>(x); // row_ror:1
+    return x;
+}
+
+__device__ __forceinline__ double readlane_f64(double x, int lane)
+{
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(x), lane), __builtin_amdgcn_readlane(__double2loint(x), lane));
+}
+// whole-wave sum / max in a fixed order, result in every lane (all 64 lanes must be active)
+__device__ __forceinline__ double wave_sum(double x)
+{
+    x = row16_sum(x);
+    return (readlane_f64(x, 0) + readlane_f64(x, 16)) + (readlane_f64(x, 32) + readlane_f64(x, 48));
+}
+__device__ __forceinline__ double wave_max(double x)
+{
+    x = fmax(x, dpp_mov<0x128>(x));
+    x = fmax(x, dpp_mov<0x124>(x));
+    x = fmax(x, dpp_mov<0x122>(x));
+    x = fmax(x, dpp_mov<0x121>(x));
+    return fmax(fmax(readlane_f64(x, 0), readlane_f64(x, 16)), fmax(readlane_f64(x, 32), readlane_f64(x, 48)));
+}
+
 struct EdgeIn {
     double z[3];
     double info[6]; // upper triangle 00 01 02 11 12 22
@@ -90,128 +127,190 @@ __device__ __forceinline__ double edge_chi2(const EdgeIn& in, const double* e)
 }
 
 // ---------------------------------------------------------------------------------------------
-// K2: landmark-major Jacobian sweep.  One lane per edge, one workgroup per run of whole landmarks
-// (<= 256 edges).  Uses the structured form of ba_math.h (J = A [-I | 2[Z]x | R']): per edge it
-// stores N = A'(rho1 Omega)A R' and Z (12 planes, fully coalesced) instead of the 6x3 block H_pl,
-// and sums H_ll = sum R N, b_l = -sum R u per landmark in a fixed order through LDS.
+// K2: landmark-major Jacobian sweep.  One lane per edge, one block = a run of whole landmarks (<= 256 edges).
+// Uses the structured form of ba_math.h (J = A [-I | 2[Z]x | R']): per edge it stores N = A'(rho1 Omega)A R' and
+// Z (12 planes, fully coalesced) instead of the 6x3 block H_pl, and sums H_ll = sum R N, b_l = -sum R u per
+// landmark in a fixed order through LDS.
+// (Measured and dropped: a persistent variant that walks several blocks per workgroup and requests the operands of
+// the next block before the tail of the current one - its register budget halves the occupancy, 38 us instead of 29.)
 // ---------------------------------------------------------------------------------------------
+template <bool DIAG>
+struct LmFetch {
+    int l0, nl, e0, e1;   // block: landmarks [l0, l0+nl), edges [e0, e1)
+    EdgeIn in;            // this lane's edge (clamped into the block)
+    int s, l;
+    int ta0[2], ta1[2];   // edge ranges (relative to e0) of the landmarks of this lane's first two sum tasks
+    bool tfix[2];
+};
+
+template <bool DIAG>
+__device__ __forceinline__ void lm_fetch(const BaDev& d, int b, LmFetch<DIAG>& f)
+{
+    const int tid = threadIdx.x;
+    f.l0 = d.lb_lm[b];
+    const int l1 = d.lb_lm[b + 1];
+    f.nl = l1 - f.l0;
+    f.e0 = d.lm_ptr[f.l0]; f.e1 = d.lm_ptr[l1];
+    const int e = min(f.e0 + tid, f.e1 - 1);
+    load_edge<DIAG>(d.e_z, d.e_info, d.e_flags, d.E, e, f.in);
+    f.s = d.e_pose[e]; f.l = d.e_lm[e];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int task = tid + q * kBlock, l = f.l0 + min(task / 9, f.nl - 1);
+        f.ta0[q] = d.lm_ptr[l] - f.e0; f.ta1[q] = d.lm_ptr[l + 1] - f.e0; f.tfix[q] = d.lm_fixed[l] != 0;
+    }
+}
+
 template <bool DIAG>
 __global__ __launch_bounds__(kBlock) void k_linearize_lm(BaDev d, int cur)
 {
-    __shared__ double s_acc[9][kLmBlockEdges];
-    __shared__ double s_red[3 * 4];
-    const int b = blockIdx.x, tid = threadIdx.x;
-    const int l0 = d.lb_lm[b], l1 = d.lb_lm[b + 1];
-    const int e0 = d.lm_ptr[l0], e1 = d.lm_ptr[l1];
+    constexpr int LDA = kLmBlockEdges + 1; // odd row stride: the nine rows of a landmark fall into different banks
+    __shared__ double s_acc[9][LDA];
+    const int tid = threadIdx.x;
     const double* __restrict__ pose = d.pose[cur];
     const double* __restrict__ lm = d.lm[cur];
-    const int E = d.E;
+    const int E = d.E, Ll = d.Ll;
 
-    double part[3] = {0.0, 0.0, 0.0}; // robust chi2, plain chi2
-    const int e = e0 + tid;
-    if (e < e1) {
-        EdgeIn in;
-        load_edge<DIAG>(d.e_z, d.e_info, d.e_flags, E, e, in);
-        const int s = d.e_pose[e], l = d.e_lm[e];
-        double R[9], t[3], p[3];
+    LmFetch<DIAG> f;
+    const int b = blockIdx.x;
+    lm_fetch<DIAG>(d, b, f);
+    {
+        const int l0 = f.l0, nl = f.nl, e0 = f.e0, e1 = f.e1;
+        const int e = e0 + tid;
+        double part[2] = {0.0, 0.0}; // robust chi2, plain chi2
+        double acc9[9];
+        if (e < e1) {
+            const EdgeIn& in = f.in;
+            const int s = f.s, l = f.l;
+            double R[9], t[3], p[3];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) R[k] = pose[12 * s + k];
+            for (int k = 0; k < 9; ++k) R[k] = pose[12 * s + k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) { t[k] = pose[12 * s + 9 + k]; p[k] = lm[3 * l + k]; }
-        double err[3], Z[3], A5[5];
-        proj_core(in.type, R, t, p, in.z, d.fx, d.fy, d.cx, d.cy, err, Z, A5);
-        const double c2 = edge_chi2(in, err);
-        double w = 1.0, r0 = c2;
-        if (in.robust) cauchy(d.cauchy_delta, c2, r0, w);
-        part[0] = r0; part[1] = c2;
-        const bool lfix = d.lm_fixed[l] != 0;
-        double O[6], C[6], u[3];
+            for (int k = 0; k < 3; ++k) { t[k] = pose[12 * s + 9 + k]; p[k] = lm[3 * l + k]; }
+            const bool lfix = d.lm_fixed[l] != 0;
+            double err[3], Z[3], A5[5];
+            proj_core(in.type, R, t, p, in.z, d.fx, d.fy, d.cx, d.cy, err, Z, A5);
+            const double c2 = edge_chi2(in, err);
+            double w = 1.0, r0 = c2;
+            if (in.robust) cauchy(d.cauchy_delta, c2, r0, w);
+            part[0] = r0; part[1] = c2;
+            double O[6], C[6], u[3];
 #pragma unroll
-        for (int k = 0; k < 6; ++k) O[k] = w * in.info[k];
-        proj_cu(A5, O, err, C, u);
-        // N = C R'  (C symmetric: c00 c01 c02 c11 c12 c22)
-        const double Cf[9] = {C[0], C[1], C[2], C[1], C[3], C[4], C[2], C[4], C[5]};
-        double N[9];
+            for (int k = 0; k < 6; ++k) O[k] = w * in.info[k];
+            proj_cu(A5, O, err, C, u);
+            // N = C R'  (C symmetric: c00 c01 c02 c11 c12 c22)
+            const double Cf[9] = {C[0], C[1], C[2], C[1], C[3], C[4], C[2], C[4], C[5]};
+            double N[9];
 #pragma unroll
-        for (int r = 0; r < 3; ++r)
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
-            for (int c = 0; c < 3; ++c) N[3 * r + c] = Cf[3 * r] * R[3 * c] + Cf[3 * r + 1] * R[3 * c + 1] + Cf[3 * r + 2] * R[3 * c + 2];
+                for (int c = 0; c < 3; ++c) N[3 * r + c] = Cf[3 * r] * R[3 * c] + Cf[3 * r + 1] * R[3 * c + 1] + Cf[3 * r + 2] * R[3 * c + 2];
 #pragma unroll
-        for (int k = 0; k < 9; ++k) d.NZ[(size_t)k * E + e] = lfix ? 0.0 : N[k];
+            for (int k = 0; k < 9; ++k) d.NZ[(size_t)k * E + e] = lfix ? 0.0 : N[k];
 #pragma unroll
-        for (int k = 0; k < 3; ++k) d.NZ[(size_t)(9 + k) * E + e] = Z[k];
-        // H_ll contribution R N (symmetric, upper 00 01 02 11 12 22) and b_l = -R u
-        int k = 0;
+            for (int k = 0; k < 3; ++k) d.NZ[(size_t)(9 + k) * E + e] = Z[k];
+            // H_ll contribution R N (symmetric, upper 00 01 02 11 12 22) and b_l = -R u
+            int k = 0;
 #pragma unroll
-        for (int a = 0; a < 3; ++a)
+            for (int a = 0; a < 3; ++a)
 #pragma unroll
-            for (int c = a; c < 3; ++c, ++k) s_acc[k][tid] = R[3 * a] * N[c] + R[3 * a + 1] * N[3 + c] + R[3 * a + 2] * N[6 + c];
+                for (int c = a; c < 3; ++c, ++k) acc9[k] = R[3 * a] * N[c] + R[3 * a + 1] * N[3 + c] + R[3 * a + 2] * N[6 + c];
 #pragma unroll
-        for (int a = 0; a < 3; ++a) s_acc[6 + a][tid] = -(R[3 * a] * u[0] + R[3 * a + 1] * u[1] + R[3 * a + 2] * u[2]);
-    }
-    __syncthreads();
-    // per-landmark sums, one (landmark, value) pair per lane: fixed order over the landmark's edges
-    double mx = 0.0;
-    const int nl = l1 - l0, Ll = d.Ll;
-    for (int task = tid; task < nl * 9; task += kBlock) {
-        const int li = task / 9, k = task - 9 * li, l = l0 + li;
-        double sum = 0.0;
-        const int a1 = d.lm_ptr[l + 1] - e0;
-        for (int a = d.lm_ptr[l] - e0; a < a1; ++a) sum += s_acc[k][a];
-        if (d.lm_fixed[l]) sum = 0.0;
-        if (k < 6) d.Hll[(size_t)k * Ll + l] = sum; else d.bl[(size_t)(k - 6) * Ll + l] = sum;
-        if (k == 0 || k == 3 || k == 5) mx = fmax(mx, fabs(sum));
-    }
-    // landmark-closure priors (EdgePointXYZ with a fixed partner, Cg2oOptimizer.cpp:448-458): rare, one lane per landmark
-    if (d.n_lmlm > 0) {
+            for (int a = 0; a < 3; ++a) acc9[6 + a] = -(R[3 * a] * u[0] + R[3 * a + 1] * u[1] + R[3 * a + 2] * u[2]);
+        }
+        if (e < e1) {
+#pragma unroll
+            for (int k = 0; k < 9; ++k) s_acc[k][tid] = acc9[k];
+        }
+        const int ta0[2] = {f.ta0[0], f.ta0[1]}, ta1[2] = {f.ta1[0], f.ta1[1]};
+        const bool tfix[2] = {f.tfix[0], f.tfix[1]};
         __syncthreads();
-        const int l = l0 + tid;
-        if (l < l1 && d.lm_ll_ptr[l + 1] > d.lm_ll_ptr[l] && !d.lm_fixed[l]) {
-            double acc[9];
+        // per-landmark sums, one (landmark, value) pair per lane: fixed order over the landmark's edges
+        double mx = 0.0;
+        auto lm_store = [&](int task, double sum, bool fixed) {
+            const int li = task / 9, k = task - 9 * li, l = l0 + li;
+            if (fixed) sum = 0.0;
+            if (k < 6) d.Hll[(size_t)k * Ll + l] = sum; else d.bl[(size_t)(k - 6) * Ll + l] = sum;
+            if (k == 0 || k == 3 || k == 5) mx = fmax(mx, fabs(sum));
+        };
+        {
+            // two tasks side by side, four LDS reads each in flight (the additions keep the edge order of the landmark)
+            int a[2], end[2];
+            const double* row[2];
+            double sum[2] = {0.0, 0.0};
 #pragma unroll
-            for (int k = 0; k < 6; ++k) acc[k] = d.Hll[(size_t)k * Ll + l];
+            for (int q = 0; q < 2; ++q) {
+                const int task = tid + q * kBlock;
+                const bool on = task < nl * 9;
+                a[q] = on ? ta0[q] : 0; end[q] = on ? ta1[q] : 0;
+                row[q] = s_acc[task % 9];
+            }
+            while (a[0] < end[0] || a[1] < end[1]) {
+                double v[2][4];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) acc[6 + k] = d.bl[(size_t)k * Ll + l];
-            for (int q = d.lm_ll_ptr[l]; q < d.lm_ll_ptr[l + 1]; ++q) {
-                double ee[3], O[6];
+                for (int q = 0; q < 2; ++q)
 #pragma unroll
-                for (int k = 0; k < 3; ++k) ee[k] = lm[3 * l + k] - d.ll_ref[3 * q + k] - d.ll_z[3 * q + k];
+                    for (int i = 0; i < 4; ++i) v[q][i] = row[q][min(a[q] + i, kLmBlockEdges - 1)];
 #pragma unroll
-                for (int k = 0; k < 6; ++k) O[k] = d.ll_info[6 * q + k];
-                const double c2 = ee[0] * (O[0] * ee[0] + 2.0 * (O[1] * ee[1] + O[2] * ee[2])) +
-                                  ee[1] * (O[3] * ee[1] + 2.0 * O[4] * ee[2]) + ee[2] * O[5] * ee[2];
-                double w = 1.0, r0 = c2;
-                if (d.ll_robust[q]) cauchy(d.cauchy_delta, c2, r0, w);
-                part[0] += r0; part[1] += c2;
+                for (int q = 0; q < 2; ++q) {
 #pragma unroll
-                for (int k = 0; k < 6; ++k) acc[k] += w * O[k];
-                acc[6] -= w * (O[0] * ee[0] + O[1] * ee[1] + O[2] * ee[2]);
-                acc[7] -= w * (O[1] * ee[0] + O[3] * ee[1] + O[4] * ee[2]);
-                acc[8] -= w * (O[2] * ee[0] + O[4] * ee[1] + O[5] * ee[2]);
+                    for (int i = 0; i < 4; ++i)
+                        if (a[q] + i < end[q]) sum[q] += v[q][i];
+                    a[q] += 4;
+                }
             }
 #pragma unroll
-            for (int k = 0; k < 6; ++k) d.Hll[(size_t)k * Ll + l] = acc[k];
-#pragma unroll
-            for (int k = 0; k < 3; ++k) d.bl[(size_t)k * Ll + l] = acc[6 + k];
-            mx = fmax(mx, fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5]))));
+            for (int q = 0; q < 2; ++q)
+                if (tid + q * kBlock < nl * 9) lm_store(tid + q * kBlock, sum[q], tfix[q]);
         }
-    }
-    // two sums and one max across the workgroup with a single barrier
-    {
-        const int lane = tid & 63, wave = tid >> 6;
-        double x0 = part[0], x1 = part[1], x2 = mx;
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            x0 += __shfl_down(x0, off, 64);
-            x1 += __shfl_down(x1, off, 64);
-            x2 = fmax(x2, __shfl_down(x2, off, 64));
+        for (int task = tid + 2 * kBlock; task < nl * 9; task += kBlock) {
+            const int li = task / 9, k = task - 9 * li, l = l0 + li;
+            double sum = 0.0;
+            const int a1 = d.lm_ptr[l + 1] - e0;
+            for (int a = d.lm_ptr[l] - e0; a < a1; ++a) sum += s_acc[k][a];
+            lm_store(task, sum, d.lm_fixed[l] != 0);
         }
-        if (lane == 0) { s_red[wave] = x0; s_red[4 + wave] = x1; s_red[8 + wave] = x2; }
-        __syncthreads();
-        if (tid == 0) {
-            d.block_part[4 * b + 0] = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-            d.block_part[4 * b + 1] = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
-            d.block_part[4 * b + 2] = fmax(fmax(s_red[8], s_red[9]), fmax(s_red[10], s_red[11]));
+        // landmark-closure priors (EdgePointXYZ with a fixed partner, Cg2oOptimizer.cpp:448-458): rare, one lane per landmark
+        if (d.n_lmlm > 0) {
+            __syncthreads();
+            const int l = l0 + tid;
+            if (tid < nl && d.lm_ll_ptr[l + 1] > d.lm_ll_ptr[l] && !d.lm_fixed[l]) {
+                double acc[9];
+#pragma unroll
+                for (int k = 0; k < 6; ++k) acc[k] = d.Hll[(size_t)k * Ll + l];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) acc[6 + k] = d.bl[(size_t)k * Ll + l];
+                for (int q = d.lm_ll_ptr[l]; q < d.lm_ll_ptr[l + 1]; ++q) {
+                    double ee[3], O[6];
+#pragma unroll
+                    for (int k = 0; k < 3; ++k) ee[k] = lm[3 * l + k] - d.ll_ref[3 * q + k] - d.ll_z[3 * q + k];
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) O[k] = d.ll_info[6 * q + k];
+                    const double c2 = ee[0] * (O[0] * ee[0] + 2.0 * (O[1] * ee[1] + O[2] * ee[2])) +
+                                      ee[1] * (O[3] * ee[1] + 2.0 * O[4] * ee[2]) + ee[2] * O[5] * ee[2];
+                    double w = 1.0, r0 = c2;
+                    if (d.ll_robust[q]) cauchy(d.cauchy_delta, c2, r0, w);
+                    part[0] += r0; part[1] += c2;
+#pragma unroll
+                    for (int k = 0; k < 6; ++k) acc[k] += w * O[k];
+                    acc[6] -= w * (O[0] * ee[0] + O[1] * ee[1] + O[2] * ee[2]);
+                    acc[7] -= w * (O[1] * ee[0] + O[3] * ee[1] + O[4] * ee[2]);
+                    acc[8] -= w * (O[2] * ee[0] + O[4] * ee[1] + O[5] * ee[2]);
+                }
+#pragma unroll
+                for (int k = 0; k < 6; ++k) d.Hll[(size_t)k * Ll + l] = acc[k];
+#pragma unroll
+                for (int k = 0; k < 3; ++k) d.bl[(size_t)k * Ll + l] = acc[6 + k];
+                mx = fmax(mx, fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5]))));
+            }
+        }
+        // two sums and one max per WAVE, in registers (DPP): no barrier, no serial tail; block_part holds one entry per wave
+        {
+            const double x0 = wave_sum(part[0]), x1 = wave_sum(part[1]), x2 = wave_max(mx);
+            if ((tid & 63) == 0) {
+                double* out = d.block_part + 4 * (size_t)(4 * b + (tid >> 6));
+                out[0] = x0; out[1] = x1; out[2] = x2;
+            }
         }
     }
 }
@@ -222,11 +321,10 @@ __global__ __launch_bounds__(kBlock) void k_linearize_lm(BaDev d, int cur)
 // in a fixed order through a small LDS buffer, nine values per pass.
 // ---------------------------------------------------------------------------------------------
 template <bool DIAG>
-__global__ __launch_bounds__(kBlock) void k_linearize_pose(BaDev d, int cur)
+__device__ __forceinline__ void sweep_pose_chunk(const BaDev& d, int cur, int c, double* smem)
 {
-    __shared__ double s_part[9][kBlock + 1];
-    __shared__ double s_q[27][8];
-    const int c = blockIdx.x, tid = threadIdx.x;
+    double (*s_part)[kBlock + 1] = reinterpret_cast<double (*)[kBlock + 1]>(smem);
+    const int tid = threadIdx.x;
     const int s = d.chunk_pose[c];
     const int e0 = d.chunk_begin[c], e1 = d.chunk_begin[c + 1];
     const double* __restrict__ pose = d.pose[cur];
@@ -241,11 +339,28 @@ __global__ __launch_bounds__(kBlock) void k_linearize_pose(BaDev d, int cur)
     double acc[27];
 #pragma unroll
     for (int k = 0; k < 27; ++k) acc[k] = 0.0;
-    for (int e = e0 + tid; e < e1; e += kBlock) {
-        EdgeIn in;
-        load_edge<DIAG>(d.pm_z, d.pm_info, d.pm_flags, E, e, in);
-        const int l = d.pm_lm[e];
-        const double p[3] = {lm[3 * l], lm[3 * l + 1], lm[3 * l + 2]};
+    // software pipeline over the (at most U) edges of a lane: the landmark indices of all of them first, then the
+    // operands of edge u+1 travel while edge u is computed.  Prefetch addresses are clamped into the chunk, so
+    // the loads need no branch; the accumulation order per lane is unchanged.
+    constexpr int U = kPoseChunk / kBlock;
+    int li[U];
+#pragma unroll
+    for (int it = 0; it < U; ++it) li[it] = d.pm_lm[min(e0 + tid + it * kBlock, e1 - 1)];
+    EdgeIn nxt;
+    double pn[3];
+    load_edge<DIAG>(d.pm_z, d.pm_info, d.pm_flags, E, min(e0 + tid, e1 - 1), nxt);
+#pragma unroll
+    for (int k = 0; k < 3; ++k) pn[k] = lm[3 * li[0] + k];
+#pragma unroll
+    for (int it = 0; it < U; ++it) {
+        const EdgeIn in = nxt;
+        const double p[3] = {pn[0], pn[1], pn[2]};
+        if (it + 1 < U) {
+            load_edge<DIAG>(d.pm_z, d.pm_info, d.pm_flags, E, min(e0 + tid + (it + 1) * kBlock, e1 - 1), nxt);
+#pragma unroll
+            for (int k = 0; k < 3; ++k) pn[k] = lm[3 * li[it + 1] + k];
+        }
+        if (e0 + tid + it * kBlock >= e1) continue;
         double err[3], Z[3], A5[5];
         proj_core(in.type, R, t, p, in.z, d.fx, d.fy, d.cx, d.cy, err, Z, A5);
         double w = 1.0, r0;
@@ -281,22 +396,38 @@ __global__ __launch_bounds__(kBlock) void k_linearize_pose(BaDev d, int cur)
         acc[25] += z2 * u[0] - z0 * u[2];
         acc[26] += -z1 * u[0] + z0 * u[1];
     }
+    // 27 sums over the 256 lanes, nine per pass: value k is summed by the 16 lanes of one DPP row (lane q takes
+    // the entries q, q+16, ...: consecutive lanes, consecutive banks), the row total by a rotate-and-add butterfly
 #pragma unroll
     for (int pass = 0; pass < 3; ++pass) {
+        if (pass) __syncthreads();
 #pragma unroll
         for (int k = 0; k < 9; ++k) s_part[k][tid] = acc[9 * pass + k];
         __syncthreads();
-        if (tid < 9 * 8) {
-            const int k = tid >> 3, q = tid & 7;
-            double sum = 0.0;
-#pragma unroll 8
-            for (int i = 0; i < 32; ++i) sum += s_part[k][q * 32 + i];
-            s_q[9 * pass + k][q] = sum;
+        if (tid < 9 * 16) {
+            const int k = tid >> 4, q = tid & 15;
+            double v[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) v[i] = s_part[k][16 * i + q];
+            double sum = v[0];
+#pragma unroll
+            for (int i = 1; i < 16; ++i) sum += v[i];
+            sum = row16_sum(sum);
+            if (q == 0) d.chunk_out[(size_t)27 * c + 9 * pass + k] = sum;
         }
-        __syncthreads();
     }
-    if (tid < 27)
-        d.chunk_out[(size_t)27 * c + tid] = ((s_q[tid][0] + s_q[tid][1]) + (s_q[tid][2] + s_q[tid][3])) + ((s_q[tid][4] + s_q[tid][5]) + (s_q[tid][6] + s_q[tid][7]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// The Jacobian sweep = two launches on the same stream: landmark-major blocks (K2) and pose-major chunks (K3).
+// (One fused launch was measured: the two kinds do not fill each other's gaps, and the fused kernel inherits the
+// register budget of the pipelined K3 loop, which halves the occupancy of the K2 blocks.)
+// ---------------------------------------------------------------------------------------------
+template <bool DIAG>
+__global__ __launch_bounds__(kBlock) void k_linearize_pose(BaDev d, int cur)
+{
+    __shared__ double smem[9 * (kBlock + 1)];
+    sweep_pose_chunk<DIAG>(d, cur, blockIdx.x, smem);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -449,7 +580,9 @@ __global__ __launch_bounds__(kBlock) void k_reduce_lin_scalars(BaDev d, int rank
     __shared__ double s_red[2 * 4];
     double part[2] = {0.0, 0.0};
     double mx = 0.0;
-    for (int b = threadIdx.x; b < d.n_lm_blocks; b += kBlock) {
+    const int n_part = 4 * d.n_lm_blocks; // one entry per wave of the sweep
+#pragma unroll 4
+    for (int b = threadIdx.x; b < n_part; b += kBlock) {
         part[0] += d.block_part[4 * b];
         part[1] += d.block_part[4 * b + 1];
         mx = fmax(mx, d.block_part[4 * b + 2]);
@@ -778,7 +911,6 @@ __global__ __launch_bounds__(kBlock) void k_backsub_chi2(BaDev d, int cur, doubl
 {
     __shared__ double s_v[3][kLmBlockEdges];
     __shared__ double s_lm[3][kLmBlockEdges];
-    __shared__ double s_red[3 * 4];
     const int b = blockIdx.x, tid = threadIdx.x;
     const int l0 = d.lb_lm[b], l1 = d.lb_lm[b + 1];
     const int e0 = d.lm_ptr[l0], e1 = d.lm_ptr[l1];
@@ -862,11 +994,12 @@ __global__ __launch_bounds__(kBlock) void k_backsub_chi2(BaDev d, int cur, doubl
         if (in.robust) cauchy(d.cauchy_delta, c2, r0, w);
         part[0] += r0; part[1] += c2;
     }
-    block_sum<3>(part, s_red);
-    if (tid == 0) {
-        d.block_part[4 * b + 0] = part[0];
-        d.block_part[4 * b + 1] = part[1];
-        d.block_part[4 * b + 2] = part[2];
+    {
+        const double x0 = wave_sum(part[0]), x1 = wave_sum(part[1]), x2 = wave_sum(part[2]);
+        if ((tid & 63) == 0) {
+            double* out = d.block_part + 4 * (size_t)(4 * b + (tid >> 6));
+            out[0] = x0; out[1] = x1; out[2] = x2;
+        }
     }
 }
 
@@ -875,7 +1008,9 @@ __global__ __launch_bounds__(kBlock) void k_reduce_trial(BaDev d)
 {
     __shared__ double s_red[3 * 4];
     double part[3] = {0.0, 0.0, 0.0};
-    for (int b = threadIdx.x; b < d.n_lm_blocks; b += kBlock) {
+    const int n_part = 4 * d.n_lm_blocks; // one entry per wave of the sweep
+#pragma unroll 4
+    for (int b = threadIdx.x; b < n_part; b += kBlock) {
         part[0] += d.block_part[4 * b];
         part[1] += d.block_part[4 * b + 1];
         part[2] += d.block_part[4 * b + 2];

@@ -253,10 +253,14 @@ class BundleAdjuster:
     def reset_phase_times(self):
         check(self._lib.svi_ba_reset_phase_times(self._h), "svi_ba_reset_phase_times")
 
-    def time_sweep(self, reps=50):
-        """mean ms of the Jacobian sweep kernel (HIP events around `reps` back-to-back launches)"""
+    def time_sweep(self, reps=50, part=0):
+        """mean ms of the Jacobian sweep (HIP events around `reps` back-to-back launches); part = 1 / 2: only the
+        landmark-major (K2) / pose-major (K3) kernel"""
         v = C.c_double(0)
-        check(self._lib.svi_ba_debug_time_sweep(self._h, int(reps), C.byref(v)), "svi_ba_debug_time_sweep")
+        if part:
+            check(self._lib.svi_ba_debug_time_sweep_part(self._h, int(reps), int(part), C.byref(v)), "svi_ba_debug_time_sweep_part")
+        else:
+            check(self._lib.svi_ba_debug_time_sweep(self._h, int(reps), C.byref(v)), "svi_ba_debug_time_sweep")
         return v.value
 
     def edge_jacobians(self):
