@@ -421,27 +421,32 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
 // ---------------------------------------------------------------------------------------------
 // trsm: L(i,k)[block] = S(i,k)[rows] * Linv_kk[cols]'      grid: (#tiles * (TS/48)^2)
 // ---------------------------------------------------------------------------------------------
+// output block edge of the trsm workgroups: 32 (four 16x16 MFMA blocks, one per wave) where the tile allows it
+template <int TS> struct TrsmBlock { static constexpr int TB = (TS % 32 == 0) ? 32 : kOB; };
+
 template <int TS>
 __global__ __launch_bounds__(kBlock) void k_trsm(const double* __restrict__ S, double* __restrict__ Lt, const double* __restrict__ Linv,
                                                  const int* __restrict__ list, const int* __restrict__ list_col, const int* status)
 {
-    constexpr int LD = Lds<TS>::LD, Q = TS / kOB;
+    constexpr int LD = Lds<TS>::LD, kTB = TrsmBlock<TS>::TB, Q = TS / kTB, NBK = kTB / 16;
+    static_assert(TS % kTB == 0 && kBlock == 256, "trsm block shape");
     extern __shared__ __align__(16) double sm[];
-    if (*status != 0) return;
+    const int failed = *status; // tested after the operand loads are on their way
     double* sA = sm;
-    double* sB = sm + kOB * LD;
+    double* sB = sm + kTB * LD;
     const int item = blockIdx.x / (Q * Q);
     const int t = list[item], k = list_col[item], qq = blockIdx.x % (Q * Q), qr = qq / Q, qc = qq % Q;
-    rows_to_lds<TS, kOB>(S + (size_t)t * TS * TS, kOB * qr, sA);
-    rows_to_lds<TS, kOB>(Linv + (size_t)k * TS * TS, kOB * qc, sB);
+    rows_to_lds<TS, kTB>(S + (size_t)t * TS * TS, kTB * qr, sA);
+    rows_to_lds<TS, kTB>(Linv + (size_t)k * TS * TS, kTB * qc, sB);
     __syncthreads();
+    if (failed != 0) return;
     double* out = Lt + (size_t)t * TS * TS;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int st = wave; st < 9; st += 4) {
-        const int r0 = (st / 3) * 16, c0 = (st % 3) * 16;
+    for (int st = wave; st < NBK * NBK; st += 4) {
+        const int r0 = (st / NBK) * 16, c0 = (st % NBK) * 16;
         const v4f64 acc = mfma_block<TS, LD>(sA, r0, sB, c0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) out[(size_t)(kOB * qr + r0 + (lane >> 4) + 4 * q) * TS + kOB * qc + c0 + (lane & 15)] = acc[q];
+        for (int q = 0; q < 4; ++q) out[(size_t)(kTB * qr + r0 + (lane >> 4) + 4 * q) * TS + kTB * qc + c0 + (lane & 15)] = acc[q];
     }
 }
 
@@ -521,15 +526,28 @@ __global__ __launch_bounds__(kPotrfThreads) void k_back_solve(const double* __re
     __shared__ double s_x[NW][TS];
     __shared__ double s_acc[TS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (*status != 0) return;
+    const int failed = *status; // tested once the first loads are on their way
     const int k = cols[blockIdx.x];
     const int q0 = p.col_ptr[k], nq = p.col_ptr[k + 1] - q0;
+    const int c0 = lane < TS ? lane : TS - 1, c1 = lane + 64 < TS ? lane + 64 : TS - 1;
+    // this wave's rows of Linv_kk for step (2): they depend on nothing, so they travel while step (1) runs
+    constexpr int RW = (TS + NW - 1) / NW;
+    double xv0[RW], xv1[RW];
+    {
+        const double* X = Linv + (size_t)k * TS * TS;
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int r = wave * RW + rr < TS ? wave * RW + rr : TS - 1;
+            xv0[rr] = X[r * TS + c0];
+            if (TS > 64) xv1[rr] = X[r * TS + c1];
+        }
+    }
+    if (failed != 0) return;
     // (1) sum_{i>k} L_ik' x_i : the sub-diagonal tiles of the column are spread over the waves, lane = column of the
     //     tile (and column + 64), rows streamed with the x_i entry broadcast from LDS
     double a0 = 0.0, a1 = 0.0;
     constexpr int RB = 24, NRB = TS / RB; // a work unit = RB rows of one tile; units go round the waves
     static_assert(TS % RB == 0 && RB % 8 == 0, "tile edge");
-    const int c0 = lane < TS ? lane : TS - 1, c1 = lane + 64 < TS ? lane + 64 : TS - 1;
     for (int u = wave; u < nq * NRB; u += NW) {
         const int q = u / NRB, rb = u % NRB;
         const double* L = Lt + (size_t)p.trsm_tile[q0 + q] * TS * TS + (size_t)rb * RB * TS;
@@ -563,24 +581,13 @@ __global__ __launch_bounds__(kPotrfThreads) void k_back_solve(const double* __re
     }
     __syncthreads();
     // (2) x_k = Linv_kk' s_acc (Linv is lower triangular): rows split over the waves
-    constexpr int RW = (TS + NW - 1) / NW;
-    const double* X = Linv + (size_t)k * TS * TS;
     double b0 = 0.0, b1 = 0.0;
-    {
-        double v0[RW], v1[RW];
 #pragma unroll
-        for (int rr = 0; rr < RW; ++rr) {
-            const int r = wave * RW + rr < TS ? wave * RW + rr : TS - 1;
-            v0[rr] = X[r * TS + c0];
-            if (TS > 64) v1[rr] = X[r * TS + c1];
-        }
-#pragma unroll
-        for (int rr = 0; rr < RW; ++rr) {
-            const int r = wave * RW + rr;
-            const double sr = r < TS ? s_acc[r < TS ? r : 0] : 0.0;
-            b0 = fma(r >= c0 ? v0[rr] : 0.0, sr, b0);   // Linv is lower triangular
-            if (TS > 64) b1 = fma(r >= c1 ? v1[rr] : 0.0, sr, b1);
-        }
+    for (int rr = 0; rr < RW; ++rr) {
+        const int r = wave * RW + rr;
+        const double sr = r < TS ? s_acc[r < TS ? r : 0] : 0.0;
+        b0 = fma(r >= c0 ? xv0[rr] : 0.0, sr, b0);   // Linv is lower triangular
+        if (TS > 64) b1 = fma(r >= c1 ? xv1[rr] : 0.0, sr, b1);
     }
     if (lane < TS) s_part[wave][lane] = b0;
     if (lane + 64 < TS) s_part[wave][lane + 64] = b1;
@@ -598,7 +605,8 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
 {
     constexpr int LD = Lds<TS>::LD, Q = TS / kOB;
     const size_t lds_p = sizeof(double) * 2 * (size_t)TS * LD;
-    const size_t lds_g = sizeof(double) * 2 * (size_t)kOB * LD;
+    constexpr int kTB = TrsmBlock<TS>::TB, QT = TS / kTB;
+    const size_t lds_g = sizeof(double) * 2 * (size_t)kTB * LD;
     static bool attr = false;
     if (!attr) {
         // a workgroup asking for more LDS than the CU has faults the queue: refuse instead of launching
@@ -618,7 +626,7 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
         sa.tgt_tile = p.tgt_tile + t0; sa.tgt_row = p.tgt_row + t0; sa.tgt_pair_ptr = p.tgt_pair_ptr + t0;
         hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(nc + ntg * Q * Q), dim3(kPotrfThreads), lds_p, s, S, Lt, Linv, g, x, n, lambda, status, 0, sa);
         const int i0 = p.h_trsm_ptr[st], ni = p.h_trsm_ptr[st + 1] - i0;
-        if (ni > 0) hipLaunchKernelGGL(k_trsm<TS>, dim3(ni * Q * Q), dim3(kBlock), lds_g, s, S, Lt, Linv, p.st_tile + i0, p.st_col + i0, status);
+        if (ni > 0) hipLaunchKernelGGL(k_trsm<TS>, dim3(ni * QT * QT), dim3(kBlock), lds_g, s, S, Lt, Linv, p.st_tile + i0, p.st_col + i0, status);
     }
     for (int st = p.n_steps - 1; st >= 0; --st) {
         const int c0 = p.h_step_ptr[st], nc = p.h_step_ptr[st + 1] - c0;
