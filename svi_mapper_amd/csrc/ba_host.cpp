@@ -38,7 +38,7 @@ void ba_assemble(const BaDev& d, void* st);
 void ba_update_poses(const BaDev& d, int cur, double lambda, void* st);
 void ba_backsub_chi2(const BaDev& d, int cur, double lambda, void* st);
 void ba_chi2_only(const BaDev& d, int which, void* st);
-void ba_reduce_trial_scalars(const BaDev& d, void* st);
+void ba_reduce_trial_scalars(const BaDev& d, int n_pub, double* h_scal, int* h_status, int seq, void* st);
 void ba_debug_jacobians(const BaDev& d, int cur, const int* e_orig, double* err, double* Jp, double* Jl, void* st);
 void ba_configure_kernels(int TS);
 int chol_potrf_probe(int tile, int reps, int stop_after, double* ms);
@@ -707,6 +707,7 @@ int build_structure(svi_ba* ba)
     SVI_TRY(dev_alloc(ba, (size_t)NT * TS * TS, &d.Linv));
     SVI_TRY(dev_alloc(ba, (size_t)NT * TS, &d.dx));
     SVI_TRY(dev_alloc(ba, 1, &d.chol_status));
+    SVI_HIP(hipMemsetAsync(d.chol_status, 0, sizeof(int), ba->stream));
     d.n_items = n_items; d.n_jobs = n_jobs; d.n_sub = n_sub;
     SVI_TRY(dev_upload(ba, it_pack, &d.it_pack));
     SVI_TRY(dev_upload(ba, job_item0, &d.job_item0));
@@ -772,20 +773,9 @@ int build_structure(svi_ba* ba)
 // ---------------------------------------------------------------------------------------------
 // LM pieces
 // ---------------------------------------------------------------------------------------------
-int read_scalars(svi_ba* ba, int n)
+// waits until the device has published sequence number `seq` (h_scal / h_status[0] are valid then)
+int wait_published(svi_ba* ba, int seq)
 {
-    if (ba->timer.on) { // profiling: a full stream synchronisation, the phase events are collected behind it
-        SVI_HIP(hipMemcpyAsync(ba->h_scal, ba->d.scal, sizeof(double) * n, hipMemcpyDeviceToHost, ba->stream));
-        SVI_HIP(hipMemcpyAsync(ba->h_status, ba->d.chol_status, sizeof(int), hipMemcpyDeviceToHost, ba->stream));
-        SVI_HIP(hipStreamSynchronize(ba->stream));
-        ba->timer.collect();
-        return SVI_OK;
-    }
-    // One LM decision per trial hangs on these few numbers: a kernel stores them into pinned host memory and the host
-    // spins on the sequence number - no copy-engine launches, no interrupt wake-up (tens of microseconds each way).
-    const int seq = ++ba->pub_seq;
-    ba_publish(ba->d, n, ba->h_scal, ba->h_status, seq, ba->stream);
-    SVI_HIP(hipGetLastError());
     volatile int* flag = ba->h_status + 1;
     for (long spin = 0;; ++spin) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
@@ -797,6 +787,41 @@ int read_scalars(svi_ba* ba, int n)
         __builtin_ia32_pause();
     }
     return SVI_OK;
+}
+
+int read_scalars(svi_ba* ba, int n)
+{
+    if (ba->timer.on) { // profiling: a full stream synchronisation, the phase events are collected behind it
+        SVI_HIP(hipMemcpyAsync(ba->h_scal, ba->d.scal, sizeof(double) * n, hipMemcpyDeviceToHost, ba->stream));
+        SVI_HIP(hipMemcpyAsync(ba->h_status, ba->d.chol_status, sizeof(int), hipMemcpyDeviceToHost, ba->stream));
+        SVI_HIP(hipMemsetAsync(ba->d.chol_status, 0, sizeof(int), ba->stream)); // handed over: clean for the next trial
+        SVI_HIP(hipStreamSynchronize(ba->stream));
+        ba->timer.collect();
+        return SVI_OK;
+    }
+    // One LM decision per trial hangs on these few numbers: a kernel stores them into pinned host memory and the host
+    // spins on the sequence number - no copy-engine launches, no interrupt wake-up (tens of microseconds each way).
+    // The publishing kernel also clears the status word for the next trial.
+    const int seq = ++ba->pub_seq;
+    ba_publish(ba->d, n, ba->h_scal, ba->h_status, seq, ba->stream);
+    SVI_HIP(hipGetLastError());
+    return wait_published(ba, seq);
+}
+
+// sums of the trial (chi2, step scale) and their way to the host; with one rank and no profiling the reduction
+// kernel publishes them itself
+int reduce_and_read_trial(svi_ba* ba, int n)
+{
+    if (ba->opt.n_ranks == 1 && !ba->timer.on) {
+        const int seq = ++ba->pub_seq;
+        ba_reduce_trial_scalars(ba->d, n, ba->h_scal, ba->h_status, seq, ba->stream);
+        SVI_HIP(hipGetLastError());
+        return wait_published(ba, seq);
+    }
+    ba_reduce_trial_scalars(ba->d, 0, nullptr, nullptr, 0, ba->stream);
+    SVI_HIP(hipGetLastError());
+    SVI_TRY(allreduce(ba, ba->d.scal, 3));
+    return read_scalars(ba, n);
 }
 
 // computeActiveErrors + buildSystem at state `cur`; leaves chi2 (robust, plain) and max|H_jj| in h_scal[0,1,5]
@@ -825,7 +850,7 @@ int trial(svi_ba* ba, double lambda, bool* failed)
     BaDev& d = ba->d;
     hipStream_t s = ba->stream;
     PhaseTimer& t = ba->timer;
-    SVI_HIP(hipMemsetAsync(d.chol_status, 0, sizeof(int), s));
+    // (the status word is clean: whoever read it last cleared it)
     t.begin(SVI_PH_SCHUR, s);
     ba_invert_landmarks(d, lambda, s);
     ba_schur(d, s);
@@ -843,11 +868,8 @@ int trial(svi_ba* ba, double lambda, bool* failed)
     t.end(s);
     t.begin(SVI_PH_CHI2, s);
     ba_chi2_aux(d, ba->cur ^ 1, ba->opt.rank, s);
-    ba_reduce_trial_scalars(d, s);
     t.end(s);
-    SVI_HIP(hipGetLastError());
-    SVI_TRY(allreduce(ba, d.scal, 3));
-    SVI_TRY(read_scalars(ba, 12));
+    SVI_TRY(reduce_and_read_trial(ba, 12));
     *failed = ba->h_status[0] != 0;
     return SVI_OK;
 }
@@ -1222,10 +1244,7 @@ int svi_ba_chi2(svi_ba* ba, double* plain, double* robust)
         SVI_HIP(hipSetDevice(ba->opt.device));
         ba_chi2_only(ba->d, ba->cur, ba->stream);
         ba_chi2_aux(ba->d, ba->cur, ba->opt.rank, ba->stream);
-        ba_reduce_trial_scalars(ba->d, ba->stream);
-        SVI_HIP(hipGetLastError());
-        SVI_TRY(allreduce(ba, ba->d.scal, 3));
-        SVI_TRY(read_scalars(ba, 8));
+        SVI_TRY(reduce_and_read_trial(ba, 8));
         ba->last_robust = ba->h_scal[0]; ba->last_plain = ba->h_scal[1]; ba->have_chi = true;
     }
     if (plain) *plain = ba->last_plain;
@@ -1471,6 +1490,7 @@ int svi_ba_debug_reduced_system(svi_ba* ba, double lambda, double* S, double* g,
     if (d.n_tiles) SVI_HIP(hipMemcpyAsync(tiles.data(), d.S, sizeof(double) * tiles.size(), hipMemcpyDeviceToHost, ba->stream));
     if (NT) SVI_HIP(hipMemcpyAsync(gv.data(), d.g, sizeof(double) * gv.size(), hipMemcpyDeviceToHost, ba->stream));
     if (NT) SVI_HIP(hipMemcpyAsync(tmap.data(), d.tile_map, sizeof(int) * tmap.size(), hipMemcpyDeviceToHost, ba->stream));
+    SVI_HIP(hipMemsetAsync(d.chol_status, 0, sizeof(int), ba->stream)); // the tap does not read it: clean for the next trial
     SVI_HIP(hipStreamSynchronize(ba->stream));
     // the tap reports the system in NATURAL free-pose order (ascending id), whatever elimination order is in use
     std::vector<int64_t> nat(n);

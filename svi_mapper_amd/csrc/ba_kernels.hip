@@ -25,8 +25,8 @@ constexpr int kBlock = 256;
 
 // ---------------------------------------------------------------------------------------------
 // block-wide sum of NV doubles held by every thread; result valid in thread 0. Fixed order.
-template <int NV>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double* s_red /* [NV][4] */)
+template <int NV, int NW = 4>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* s_red /* [NV][NW] */)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
@@ -34,26 +34,58 @@ __device__ __forceinline__ void block_sum(double (&v)[NV], double* s_red /* [NV]
         double x = v[k];
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-        if (lane == 0) s_red[k * 4 + wave] = x;
+        if (lane == 0) s_red[k * NW + wave] = x;
     }
     __syncthreads();
     if (threadIdx.x == 0) {
 #pragma unroll
-        for (int k = 0; k < NV; ++k) v[k] = (s_red[k * 4] + s_red[k * 4 + 1]) + (s_red[k * 4 + 2] + s_red[k * 4 + 3]);
+        for (int k = 0; k < NV; ++k) {
+            if (NW == 4) v[k] = (s_red[k * 4] + s_red[k * 4 + 1]) + (s_red[k * 4 + 2] + s_red[k * 4 + 3]);
+            else {
+                double t = s_red[k * NW];
+#pragma unroll
+                for (int w = 1; w < NW; ++w) t += s_red[k * NW + w];
+                v[k] = t;
+            }
+        }
     }
     __syncthreads();
 }
 
-__device__ __forceinline__ double block_max(double x, double* s_red /* [4] */)
+template <int NW = 4>
+__device__ __forceinline__ double block_max(double x, double* s_red /* [NW] */)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) x = fmax(x, __shfl_down(x, off, 64));
     if (lane == 0) s_red[wave] = x;
     __syncthreads();
-    const double r = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+    double r = s_red[0];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) r = fmax(r, s_red[w]);
     __syncthreads();
     return r;
+}
+
+// the per-wave partials of the landmark-major kernels ([entry][4] doubles): a thread takes entries tid, tid + NT, ...,
+// one 32-byte load each, kRedBatch of them in flight together
+constexpr int kRedThreads = 1024, kRedBatch = 14;
+struct alignas(32) Part4 { double v[4]; };
+template <typename F>
+__device__ __forceinline__ void for_each_part(const double* __restrict__ block_part, int n_part, F&& f)
+{
+    const Part4* __restrict__ src = reinterpret_cast<const Part4*>(block_part);
+    for (int base = 0; base < n_part; base += kRedBatch * kRedThreads) {
+        Part4 e[kRedBatch];
+#pragma unroll
+        for (int i = 0; i < kRedBatch; ++i) {
+            const int b = base + (int)threadIdx.x + i * kRedThreads;
+            e[i] = src[b < n_part ? b : 0];
+        }
+#pragma unroll
+        for (int i = 0; i < kRedBatch; ++i)
+            if (base + (int)threadIdx.x + i * kRedThreads < n_part) f(e[i]);
+    }
 }
 
 // sum over the 16 lanes of a DPP row (every lane of the row gets the same bits): rotate-and-add butterfly
@@ -575,20 +607,15 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(BaDev d, const int* __
 }
 
 // chi2 (robust, plain) of the linearisation point and this rank's max |diag H_ll|.
-__global__ __launch_bounds__(kBlock) void k_reduce_lin_scalars(BaDev d, int rank, int n_ranks)
+__global__ __launch_bounds__(kRedThreads) void k_reduce_lin_scalars(BaDev d, int rank, int n_ranks)
 {
-    __shared__ double s_red[2 * 4];
+    constexpr int NW = kRedThreads / 64;
+    __shared__ double s_red[2 * NW];
     double part[2] = {0.0, 0.0};
     double mx = 0.0;
-    const int n_part = 4 * d.n_lm_blocks; // one entry per wave of the sweep
-#pragma unroll 4
-    for (int b = threadIdx.x; b < n_part; b += kBlock) {
-        part[0] += d.block_part[4 * b];
-        part[1] += d.block_part[4 * b + 1];
-        mx = fmax(mx, d.block_part[4 * b + 2]);
-    }
-    block_sum<2>(part, s_red);
-    mx = block_max(mx, s_red);
+    for_each_part(d.block_part, 4 * d.n_lm_blocks, [&](const Part4& e) { part[0] += e.v[0]; part[1] += e.v[1]; mx = fmax(mx, e.v[2]); });
+    block_sum<2, NW>(part, s_red);
+    mx = block_max<NW>(mx, s_red);
     if (threadIdx.x == 0) {
         d.lin_scal[0] = part[0] + d.scal[6];
         d.lin_scal[1] = part[1] + d.scal[7];
@@ -596,23 +623,30 @@ __global__ __launch_bounds__(kBlock) void k_reduce_lin_scalars(BaDev d, int rank
     }
 }
 
-// max |H_jj| over all free vertices (g2o computeLambdaInit) -> scal[5]; also copies chi2 to scal[0..1]
-__global__ __launch_bounds__(kBlock) void k_lin_post(BaDev d, int n_ranks)
+// max |H_jj| over all free vertices (g2o computeLambdaInit) -> scal[5]; also copies chi2 to scal[0..1].
+// SINGLE (one rank, nothing to exchange in between): the sums of k_reduce_lin_scalars are done here as well.
+template <bool SINGLE>
+__global__ __launch_bounds__(kRedThreads) void k_lin_post(BaDev d, int n_ranks)
 {
-    __shared__ double s_red[4];
+    constexpr int NW = kRedThreads / 64;
+    __shared__ double s_red[2 * NW];
     double mx = 0.0;
-    for (int i = threadIdx.x; i < d.Pf * 6; i += kBlock) {
+    double part[2] = {0.0, 0.0};
+    if (SINGLE) for_each_part(d.block_part, 4 * d.n_lm_blocks, [&](const Part4& e) { part[0] += e.v[0]; part[1] += e.v[1]; mx = fmax(mx, e.v[2]); });
+    for (int i = threadIdx.x; i < d.Pf * 6; i += kRedThreads) {
         const int r = i / 6, a = i % 6;
         // diagonal entry a of the upper-triangle packing: index = a*6 - a(a-1)/2
         mx = fmax(mx, fabs(d.Hpp[(size_t)21 * r + (a * 6 - a * (a - 1) / 2)]));
     }
-    for (int k = threadIdx.x; k < n_ranks; k += kBlock) mx = fmax(mx, d.lin_scal[2 + k]);
-    mx = block_max(mx, s_red);
+    if (SINGLE) block_sum<2, NW>(part, s_red);
+    else for (int k = threadIdx.x; k < n_ranks; k += kRedThreads) mx = fmax(mx, d.lin_scal[2 + k]);
+    mx = block_max<NW>(mx, s_red);
     // slots 8..10 carry the same numbers and survive the trial kernels (which rewrite 0..3): the host may pick them up
     // together with the trial results instead of waiting here
     if (threadIdx.x == 0) {
-        d.scal[5] = mx; d.scal[0] = d.lin_scal[0]; d.scal[1] = d.lin_scal[1];
-        d.scal[8] = d.lin_scal[0]; d.scal[9] = d.lin_scal[1]; d.scal[10] = mx;
+        const double c0 = SINGLE ? part[0] + d.scal[6] : d.lin_scal[0], c1 = SINGLE ? part[1] + d.scal[7] : d.lin_scal[1];
+        d.scal[5] = mx; d.scal[0] = c0; d.scal[1] = c1;
+        d.scal[8] = c0; d.scal[9] = c1; d.scal[10] = mx;
     }
 }
 
@@ -1003,23 +1037,36 @@ __global__ __launch_bounds__(kBlock) void k_backsub_chi2(BaDev d, int cur, doubl
     }
 }
 
-// scal[0] robust chi2, scal[1] plain chi2, scal[2] landmark part of the step scale (trial state)
-__global__ __launch_bounds__(kBlock) void k_reduce_trial(BaDev d)
+// the few numbers of an LM decision go straight into pinned host memory, the sequence number last (system-scope
+// release); the host spins on the sequence number (ba_host.cpp read_scalars).  The status word is handed over and
+// cleared for the next trial.  Called by the first n (<= 64) threads of a workgroup after a barrier.
+__device__ __forceinline__ void publish_scalars(const double* scal, int n, int* status, double* h_scal, int* h_status, int seq)
 {
-    __shared__ double s_red[3 * 4];
+    if ((int)threadIdx.x < n) __hip_atomic_store(h_scal + threadIdx.x, scal[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    if (threadIdx.x == 0) { __hip_atomic_store(h_status, *status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM); *status = 0; }
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) __hip_atomic_store(h_status + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// scal[0] robust chi2, scal[1] plain chi2, scal[2] landmark part of the step scale (trial state);
+// n_pub > 0 (one rank): publishes scal[0..n_pub) to the host in the same launch
+__global__ __launch_bounds__(kRedThreads) void k_reduce_trial(BaDev d, int n_pub, double* h_scal, int* h_status, int seq)
+{
+    constexpr int NW = kRedThreads / 64;
+    __shared__ double s_red[3 * NW];
     double part[3] = {0.0, 0.0, 0.0};
-    const int n_part = 4 * d.n_lm_blocks; // one entry per wave of the sweep
-#pragma unroll 4
-    for (int b = threadIdx.x; b < n_part; b += kBlock) {
-        part[0] += d.block_part[4 * b];
-        part[1] += d.block_part[4 * b + 1];
-        part[2] += d.block_part[4 * b + 2];
-    }
-    block_sum<3>(part, s_red);
+    for_each_part(d.block_part, 4 * d.n_lm_blocks, [&](const Part4& e) { part[0] += e.v[0]; part[1] += e.v[1]; part[2] += e.v[2]; });
+    block_sum<3, NW>(part, s_red);
     if (threadIdx.x == 0) {
         d.scal[0] = part[0] + d.scal[6];
         d.scal[1] = part[1] + d.scal[7];
         d.scal[2] = part[2];
+    }
+    if (n_pub > 0) {
+        __threadfence();
+        __syncthreads();
+        publish_scalars(d.scal, n_pub, d.chol_status, h_scal, h_status, seq);
     }
 }
 
@@ -1065,14 +1112,9 @@ void ba_linearize_pose(const BaDev& d, int cur, void* st)
 }
 // Results for the host without a copy engine round trip: the scalars go straight into pinned host memory, the
 // sequence number last (system-scope release); the host spins on the sequence number (ba_host.cpp read_scalars).
-__global__ __launch_bounds__(64) void k_publish(const double* __restrict__ scal, int n, const int* __restrict__ status, double* h_scal,
-                                                int* h_status, int seq)
+__global__ __launch_bounds__(64) void k_publish(const double* __restrict__ scal, int n, int* status, double* h_scal, int* h_status, int seq)
 {
-    if ((int)threadIdx.x < n) __hip_atomic_store(h_scal + threadIdx.x, scal[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    if (threadIdx.x == 0) __hip_atomic_store(h_status, *status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    __threadfence_system();
-    __syncthreads();
-    if (threadIdx.x == 0) __hip_atomic_store(h_status + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    publish_scalars(scal, n, status, h_scal, h_status, seq);
 }
 
 void ba_publish(const BaDev& d, int n, double* h_scal, int* h_status, int seq, void* st)
@@ -1091,11 +1133,12 @@ void ba_chi2_aux(const BaDev& d, int which, int, void* st)
 void ba_pose_finalize(const BaDev& d, const int* red_slot, int rank, int n_ranks, void* st)
 {
     if (d.Pf > 0) hipLaunchKernelGGL(k_pose_finalize, dim3((d.Pf * 27 + kBlock - 1) / kBlock), dim3(kBlock), 0, S_(st), d, red_slot);
-    hipLaunchKernelGGL(k_reduce_lin_scalars, dim3(1), dim3(kBlock), 0, S_(st), d, rank, n_ranks);
+    if (n_ranks > 1) hipLaunchKernelGGL(k_reduce_lin_scalars, dim3(1), dim3(kRedThreads), 0, S_(st), d, rank, n_ranks);
 }
 void ba_lin_post(const BaDev& d, int n_ranks, void* st)
 {
-    hipLaunchKernelGGL(k_lin_post, dim3(1), dim3(kBlock), 0, S_(st), d, n_ranks);
+    if (n_ranks > 1) hipLaunchKernelGGL(k_lin_post<false>, dim3(1), dim3(kRedThreads), 0, S_(st), d, n_ranks);
+    else hipLaunchKernelGGL(k_lin_post<true>, dim3(1), dim3(kRedThreads), 0, S_(st), d, n_ranks);
 }
 void ba_invert_landmarks(const BaDev& d, double lambda, void* st)
 {
@@ -1125,9 +1168,9 @@ void ba_chi2_only(const BaDev& d, int which, void* st)
     if (d.info_planes == 3) hipLaunchKernelGGL((k_backsub_chi2<false, true>), dim3(d.n_lm_blocks), dim3(kBlock), 0, S_(st), d, which, 0.0);
     else hipLaunchKernelGGL((k_backsub_chi2<false, false>), dim3(d.n_lm_blocks), dim3(kBlock), 0, S_(st), d, which, 0.0);
 }
-void ba_reduce_trial_scalars(const BaDev& d, void* st)
+void ba_reduce_trial_scalars(const BaDev& d, int n_pub, double* h_scal, int* h_status, int seq, void* st)
 {
-    hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(kBlock), 0, S_(st), d);
+    hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(kRedThreads), 0, S_(st), d, n_pub, h_scal, h_status, seq);
 }
 void ba_debug_jacobians(const BaDev& d, int cur, const int* e_orig, double* err, double* Jp, double* Jl, void* st)
 {
