@@ -84,6 +84,7 @@ struct BaDev {
     double* Hll;      // [6][Ll]  upper triangle of H_ll
     double* bl;       // [3][Ll]
     double* Hinv;     // [6][Ll]  (H_ll + lambda I)^-1, per trial
+    double* HinvB;    // [Ll][12] the same inverse (6) and b_l (3) as one record per landmark: what the Schur kernel stages
     double* chunk_out;// [n_chunks][27]  21 (upper of 6x6) + 6
     double* se3_out;  // [n_se3][120]  Hii(36) Hjj(36) Hij(36) bi(6) bj(6)
     double* acc_out;  // [n_accel][42] H(36) b(6)
@@ -107,15 +108,18 @@ struct BaDev {
     double* dx;            // [NT*TS] solution (pose increments)
     int*    chol_status;   // [1] 0 ok, k+1: pivot failure in tile column k
 
-    // Schur reduction on 48 x 48 sub-tiles (8 x 8 poses): items, wavefront jobs, slabs
+    // Schur reduction: cells of 4 x 4 poses (four per stored 48 x 48 sub-tile: cell = 4 sub + 2 u + v), items
+    // (landmark x cell), quarter jobs (runs of items of one cell, 16 lanes), wavefront jobs (4 quarter jobs), slabs
     int n_items, n_jobs, n_sub;
     const int* it_pack;      // [n_items][4]: landmark, first edge of the row segment, first edge of the column segment, maskI | maskJ << 8
-    const int* job_item0;    // [n_jobs+1]
-    const int* job_diag;     // [n_jobs] 1: diagonal sub-tile (lower blocks only, carries g)
-    double* slab;            // [n_jobs][36][64]  element q of the 6x6 block of lane (i = lane>>3, j = lane&7)
-    double* gslab;           // [n_jobs][6][8]
-    // assembly per stored sub-tile
-    const int* sub_job_ptr;  // [n_sub+1] (jobs of a sub-tile are consecutive)
+    const int* qj_begin;     // [4 n_jobs] first item of quarter job 4 job + quarter
+    const int* qj_end;       // [4 n_jobs]
+    const int* qj_diag;      // [4 n_jobs] 1: diagonal cell (lower blocks only, carries g)
+    const int* job_len;      // [n_jobs] longest of the four quarter jobs
+    double* slab;            // [n_jobs][36][64]  element q of the 6x6 block of lane (quarter = lane>>4, i = (lane>>2)&3, j = lane&3)
+    double* gslab;           // [4 n_jobs][6][4]
+    const int* cell_qj_ptr;  // [4 n_sub + 1] quarter jobs of a cell, in summation order
+    const int* cell_qj;
     const int* sub_cx;       // [n_sub] sub-tile row / column in units of 48
     const int* sub_cy;
     const int* sub_tile;     // [n_sub] tile id that holds it

@@ -574,7 +574,13 @@ int build_structure(svi_ba* ba)
                 sub_cx.push_back(cx); sub_cy.push_back(cy); sub_tile.push_back(t);
             }
     const int n_sub = (int)sub_cx.size();
-    struct Item { int sub, lm, a0, b0, masks; };
+    // Schur work list.  A stored 48 x 48 sub-tile is four CELLS of 4 x 4 poses (24 x 24); an item is one landmark in one
+    // cell: its edges to the cell's row poses and to its column poses (masks over the four poses of each).  Cells of
+    // four poses instead of eight raise the share of (pose, pose) lanes that have work from 36 % to 61 % at KITTI-like
+    // co-visibility.  A quarter job is a run of <= L items of one cell, a wavefront job four quarter jobs of similar
+    // length (one per group of 16 lanes), so that the four quarters of a wave finish together.
+    constexpr int PQ = 4;
+    struct Item { int cell, lm, a0, b0, masks; };
     std::vector<Item> items;
     int64_t total_pairs = 0;
     for (int l = 0; l < Ll; ++l) {
@@ -585,40 +591,72 @@ int build_structure(svi_ba* ba)
         struct Seg { int chunk, begin, mask, count; };
         std::vector<Seg> seg;
         while (a < end) {
-            const int c = pose_red[e_pose[a]] / PBS;
+            const int c = pose_red[e_pose[a]] / PQ;
             Seg sg{c, a, 0, 0};
-            while (a < end && pose_red[e_pose[a]] / PBS == c) { sg.mask |= 1 << (pose_red[e_pose[a]] % PBS); ++sg.count; ++a; }
+            while (a < end && pose_red[e_pose[a]] / PQ == c) { sg.mask |= 1 << (pose_red[e_pose[a]] % PQ); ++sg.count; ++a; }
             seg.push_back(sg);
         }
         for (size_t x = 0; x < seg.size(); ++x)
             for (size_t y = 0; y <= x; ++y) {
-                const int sub = sub_map[(size_t)seg[x].chunk * NSUB + seg[y].chunk];
+                const int qx = seg[x].chunk, qy = seg[y].chunk; // qx >= qy: edges of a landmark ascend in reduced index
+                if (qy > qx) return fail(SVI_ERR_STATE, "internal: landmark edges not in reduced pose order");
+                const int sub = sub_map[(size_t)(qx / 2) * NSUB + qy / 2];
                 if (sub < 0) return fail(SVI_ERR_STATE, "internal: Schur sub-tile outside the tile structure");
-                items.push_back({sub, l, seg[x].begin, seg[y].begin, seg[x].mask | (seg[y].mask << 8)});
+                items.push_back({4 * sub + 2 * (qx % 2) + (qy % 2), l, seg[x].begin, seg[y].begin, seg[x].mask | (seg[y].mask << 8)});
                 total_pairs += (x == y) ? (int64_t)seg[x].count * (seg[x].count + 1) / 2 : (int64_t)seg[x].count * seg[y].count;
             }
     }
-    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.sub < b.sub; });
+    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.cell < b.cell; });
     const int n_items = (int)items.size();
     std::vector<int> it_pack((size_t)4 * std::max(n_items, 1));
     for (int i = 0; i < n_items; ++i) {
         it_pack[4 * i] = items[i].lm; it_pack[4 * i + 1] = items[i].a0; it_pack[4 * i + 2] = items[i].b0; it_pack[4 * i + 3] = items[i].masks;
     }
-    // ~1.6 wavefront jobs per SIMD of the chip (measured: more, shorter jobs only move work into k_assemble)
-    const int target = (int)std::min<int64_t>(1024, std::max<int64_t>(16, n_items / 1536));
-    std::vector<int> job_item0(1, 0), job_sub;
+    // quarter jobs: about one wavefront job per SIMD of the chip.  Measured at config 4: the kernel takes the same
+    // 240-247 us from 3500 to 8192 quarter jobs (it is bound by instructions per pass, not by occupancy), while the
+    // assemble kernel's time grows with the number of slabs.
+    const int n_cells = 4 * n_sub;
+    int n_cu = 256;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ba->opt.device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
+    const int64_t qj_cap = getenv("SVI_SCHUR_QJ") ? atoi(getenv("SVI_SCHUR_QJ")) : (int64_t)4 * (n_cu * 4);
+    std::vector<int> cell_count;
+    for (int i = 0; i < n_items;) { int j = i; while (j < n_items && items[j].cell == items[i].cell) ++j; cell_count.push_back(j - i); i = j; }
+    auto pieces = [&](int len) { int64_t n = 0; for (int c : cell_count) n += (c + len - 1) / len; return n; };
+    int L = 16;
+    while (L < 1024 && pieces(L) > qj_cap) ++L;
+    struct QJob { int begin, end, cell; };
+    std::vector<QJob> qjobs;
     for (int i = 0; i < n_items;) {
-        const int sub = items[i].sub;
+        const int cell = items[i].cell;
         int j = i;
-        while (j < n_items && items[j].sub == sub && j - i < target) ++j;
-        job_sub.push_back(sub);
-        job_item0.push_back(j);
+        while (j < n_items && items[j].cell == cell && j - i < L) ++j;
+        qjobs.push_back({i, j, cell});
         i = j;
     }
-    const int n_jobs = (int)job_sub.size();
-    std::vector<int> sub_job_ptr(n_sub + 1, 0), job_diag(std::max(n_jobs, 1), 0);
-    for (int j = 0; j < n_jobs; ++j) { sub_job_ptr[job_sub[j] + 1]++; job_diag[j] = sub_cx[job_sub[j]] == sub_cy[job_sub[j]]; }
-    for (int t = 0; t < n_sub; ++t) sub_job_ptr[t + 1] += sub_job_ptr[t]; // jobs of a sub-tile are consecutive
+    // waves take four quarter jobs of similar length; the slabs of a cell are summed in the order of its pieces
+    std::vector<int> qorder(qjobs.size());
+    for (size_t i = 0; i < qorder.size(); ++i) qorder[i] = (int)i;
+    std::stable_sort(qorder.begin(), qorder.end(), [&](int a, int b) { return qjobs[a].end - qjobs[a].begin > qjobs[b].end - qjobs[b].begin; });
+    const int n_jobs = ((int)qjobs.size() + 3) / 4;
+    std::vector<int> qj_begin((size_t)4 * std::max(n_jobs, 1), 0), qj_end((size_t)4 * std::max(n_jobs, 1), 0), qj_diag((size_t)4 * std::max(n_jobs, 1), 0);
+    std::vector<int> job_len(std::max(n_jobs, 1), 0), slot_of(qjobs.size(), -1);
+    for (size_t k = 0; k < qorder.size(); ++k) {
+        const QJob& q = qjobs[qorder[k]];
+        qj_begin[k] = q.begin; qj_end[k] = q.end;
+        const int sub = q.cell / 4, u = (q.cell / 2) % 2, v = q.cell % 2;
+        qj_diag[k] = (sub_cx[sub] == sub_cy[sub] && u == v) ? 1 : 0;
+        job_len[k / 4] = std::max(job_len[k / 4], q.end - q.begin);
+        slot_of[qorder[k]] = (int)k;
+    }
+    std::vector<int> cell_qj_ptr(n_cells + 1, 0), cell_qj;
+    {
+        size_t k = 0;
+        for (int c = 0; c < n_cells; ++c) {
+            cell_qj_ptr[c] = (int)cell_qj.size();
+            while (k < qjobs.size() && qjobs[k].cell == c) { cell_qj.push_back(slot_of[k]); ++k; } // qjobs ascend in cell
+        }
+        cell_qj_ptr[n_cells] = (int)cell_qj.size();
+    }
     std::vector<std::vector<int>> taux(n_sub);
     for (int k = 0; k < (int)se3_i.size(); ++k) {
         const int ri = pose_red[se3_i[k]], rj = pose_red[se3_j[k]];
@@ -690,6 +728,7 @@ int build_structure(svi_ba* ba)
     SVI_TRY(dev_alloc(ba, (size_t)6 * Ll, &d.Hll));
     SVI_TRY(dev_alloc(ba, (size_t)3 * Ll, &d.bl));
     SVI_TRY(dev_alloc(ba, (size_t)6 * Ll, &d.Hinv));
+    SVI_TRY(dev_alloc(ba, (size_t)12 * std::max(Ll, 1), &d.HinvB));
     SVI_TRY(dev_alloc(ba, (size_t)27 * n_chunks, &d.chunk_out));
     SVI_TRY(dev_alloc(ba, (size_t)120 * d.n_se3, &d.se3_out));
     SVI_TRY(dev_alloc(ba, (size_t)42 * d.n_accel, &d.acc_out));
@@ -710,11 +749,14 @@ int build_structure(svi_ba* ba)
     SVI_HIP(hipMemsetAsync(d.chol_status, 0, sizeof(int), ba->stream));
     d.n_items = n_items; d.n_jobs = n_jobs; d.n_sub = n_sub;
     SVI_TRY(dev_upload(ba, it_pack, &d.it_pack));
-    SVI_TRY(dev_upload(ba, job_item0, &d.job_item0));
-    SVI_TRY(dev_upload(ba, job_diag, &d.job_diag));
+    SVI_TRY(dev_upload(ba, qj_begin, &d.qj_begin));
+    SVI_TRY(dev_upload(ba, qj_end, &d.qj_end));
+    SVI_TRY(dev_upload(ba, qj_diag, &d.qj_diag));
+    SVI_TRY(dev_upload(ba, job_len, &d.job_len));
     SVI_TRY(dev_alloc(ba, (size_t)std::max(n_jobs, 1) * 36 * 64, &d.slab, false));
-    SVI_TRY(dev_alloc(ba, (size_t)std::max(n_jobs, 1) * 6 * 8, &d.gslab, false));
-    SVI_TRY(dev_upload(ba, sub_job_ptr, &d.sub_job_ptr));
+    SVI_TRY(dev_alloc(ba, (size_t)std::max(n_jobs, 1) * 4 * 6 * 4, &d.gslab, false));
+    SVI_TRY(dev_upload(ba, cell_qj_ptr, &d.cell_qj_ptr));
+    SVI_TRY(dev_upload(ba, cell_qj, &d.cell_qj));
     SVI_TRY(dev_upload(ba, sub_cx, &d.sub_cx));
     SVI_TRY(dev_upload(ba, sub_cy, &d.sub_cy));
     SVI_TRY(dev_upload(ba, sub_tile, &d.sub_tile));

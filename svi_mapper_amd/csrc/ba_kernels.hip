@@ -675,70 +675,91 @@ __global__ __launch_bounds__(kBlock) void k_invert_landmarks(BaDev d, double lam
     }
 #pragma unroll
     for (int k = 0; k < 6; ++k) d.Hinv[(size_t)k * Ll + l] = inv[k];
+    // one contiguous record per landmark for the Schur staging (a single cache line instead of nine planes)
+    double* rec = d.HinvB + (size_t)12 * l;
+#pragma unroll
+    for (int k = 0; k < 6; ++k) rec[k] = inv[k];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) rec[6 + k] = d.bl[(size_t)k * Ll + l];
 }
 
 // ---------------------------------------------------------------------------------------------
-// K4: Schur reduction on 48 x 48 sub-tiles of S.  One WAVEFRONT per job (a run of items of one
-// sub-tile); lane (i,j) = (lane>>3, lane&7) owns the 6x6 block of pose pair (8 cX + i, 8 cY + j) and
-// accumulates it in registers: for every item (landmark) whose masks contain both poses,
+// K4: Schur reduction on CELLS of 4 x 4 poses (24 x 24 entries of S).  One WAVEFRONT per job = four quarter jobs
+// (runs of items of one cell each); lane = (quarter, i, j) = (lane>>4, (lane>>2)&3, lane&3) owns the 6x6 block of
+// pose pair (4 cX + i, 4 cY + j) of its quarter's cell and accumulates it in registers: for every item (landmark)
+// of the quarter job whose masks contain both poses,
 //     block += (W_a Hinv_l) W_b'        (a, b = the landmark's edges to those two poses)
-// No atomics, fixed summation order.  Diagonal sub-tiles keep the lower blocks only and carry the
-// right-hand side  g_i += (W_a Hinv_l) b_l.
+// No atomics, fixed summation order.  Diagonal cells keep the lower blocks only and carry the right-hand side
+// g_i += (W_a Hinv_l) b_l.  The kernel is FP64-instruction bound: four-pose cells give 61 % of the
+// lanes work at KITTI-like co-visibility where eight-pose cells gave 36 %.
 // ---------------------------------------------------------------------------------------------
-constexpr int kSchurBatch = 4;             // items staged per wave and pass
-constexpr int kSchurSlot  = 16 * 12 + 12;  // doubles per staged item: 16 edge slots x (N 9, Z 3), then Hinv(6), b_l(3), pad
+constexpr int kSchurBatch = 2;        // passes (one item per quarter) staged per wave and buffer
+constexpr int kSchurSlot  = 115;      // doubles per staged item: 8 edge slots x (N 9, Z 3), Hinv(6), b_l(3), pad; odd
+                                      // multiple chosen so that the 16 (quarter, pose) operand rows sit in 16 different bank pairs
 
-struct SchurStage { double v[kSchurBatch][3]; double hv[kSchurBatch]; };
+struct SchurStage { double v[kSchurBatch][6]; double hv[kSchurBatch]; int m[kSchurBatch]; };
 
-// issue the global loads of the items [base, base+nb) of a job.  Staging role of a lane: edge slot es
-// (0..7 row segment, 8..15 column segment) and planes pg, pg+4, pg+8 of the 12 (N, Z) planes.
-__device__ __forceinline__ void schur_fetch(const BaDev& d, const int4* __restrict__ items, int base, int nb, bool diag, int lane,
-                                            SchurStage& st)
+// item records of the passes [base, base + kSchurBatch) of this lane's quarter job (zero mask beyond its end)
+__device__ __forceinline__ void schur_fetch_items(const int4* __restrict__ items, int it0, int it1, int base, int4 (&pk)[kSchurBatch])
 {
-    const int es = lane & 15, pg = lane >> 4;
-    const size_t E = d.E, Ll = d.Ll;
 #pragma unroll
     for (int t = 0; t < kSchurBatch; ++t) {
-        if (t < nb) {
-            const int4 pk = items[base + t];
-            const unsigned mI = (unsigned)pk.w & 0xFFu, mJ = ((unsigned)pk.w >> 8) & 0xFFu;
-            const int nI = __popc(mI), nJ = diag ? 0 : __popc(mJ);
-            long long e = -1;
-            if (es < 8) { if (es < nI) e = (long long)pk.y + es; }
-            else if (es - 8 < nJ) e = (long long)pk.z + (es - 8);
-#pragma unroll
-            for (int q = 0; q < 3; ++q) st.v[t][q] = (e >= 0) ? d.NZ[(size_t)(pg + 4 * q) * E + (size_t)e] : 0.0;
-            st.hv[t] = (lane < 6) ? d.Hinv[(size_t)lane * Ll + pk.x] : ((lane < 9) ? d.bl[(size_t)(lane - 6) * Ll + pk.x] : 0.0);
-        }
+        const int it = it0 + base + t;
+        pk[t] = items[it < it1 ? it : it0];
+        if (it >= it1) pk[t].w = 0;
     }
 }
 
-__device__ __forceinline__ void schur_stash(const SchurStage& st, int nb, int lane, double (*slots)[kSchurSlot])
+// issue the operand loads of the passes whose item records are `pk`.  Staging role of a lane inside its quarter:
+// edge slot es (0..3 row segment, 4..7 column segment) and planes 6 pg .. 6 pg + 5 of the 12 (N, Z) planes.
+__device__ __forceinline__ void schur_fetch(const BaDev& d, const int4 (&pk)[kSchurBatch], bool diag, int lane, SchurStage& st)
 {
-    const int es = lane & 15, pg = lane >> 4;
+    const int es = lane & 7, pg = (lane >> 3) & 1, l16 = lane & 15;
+    const size_t E = d.E;
+    const double* __restrict__ plane0 = d.NZ + (size_t)(6 * pg) * E; // this lane's first plane
 #pragma unroll
     for (int t = 0; t < kSchurBatch; ++t) {
-        if (t < nb) {
+        st.m[t] = pk[t].w;
+        const unsigned mI = (unsigned)pk[t].w & 0xFu, mJ = ((unsigned)pk[t].w >> 8) & 0xFu;
+        const int nI = __popc(mI), nJ = diag ? 0 : __popc(mJ);
+        // unconditional loads from a clamped edge (edge 0 for an empty slot), the value masked afterwards: no
+        // divergent regions around the loads
+        const bool row = es < 4;
+        const bool on = row ? (es < nI) : (es - 4 < nJ);
+        const unsigned e = on ? (unsigned)((row ? pk[t].y : pk[t].z - 4) + es) : 0u;
+        const double* __restrict__ src = plane0 + e;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) slots[t][es * 12 + pg + 4 * q] = st.v[t][q];
-            if (lane < 9) slots[t][192 + lane] = st.hv[t];
-        }
+        for (int q = 0; q < 6; ++q) { const double x = src[(size_t)q * E]; st.v[t][q] = on ? x : 0.0; }
+        const double h = d.HinvB[(size_t)12 * (unsigned)pk[t].x + (l16 < 9 ? l16 : 0)];
+        st.hv[t] = (pk[t].w != 0 && l16 < 9) ? h : 0.0;
+    }
+}
+
+__device__ __forceinline__ void schur_stash(const SchurStage& st, int lane, double (*slots)[4][kSchurSlot])
+{
+    const int es = lane & 7, pg = (lane >> 3) & 1, l16 = lane & 15, qt = lane >> 4;
+#pragma unroll
+    for (int t = 0; t < kSchurBatch; ++t) {
+#pragma unroll
+        for (int q = 0; q < 6; ++q) slots[t][qt][es * 12 + 6 * pg + q] = st.v[t][q];
+        if (l16 < 9) slots[t][qt][96 + l16] = st.hv[t];
     }
 }
 
 __global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
 {
-    // The operands of kSchurBatch items are staged in a wave-private LDS region, double buffered: the
+    // The operands of kSchurBatch passes are staged in a wave-private LDS region, double buffered: the
     // global loads of batch k+1 are in flight while batch k is being multiplied out of LDS.
     // Block of pose pair (a,b) for one landmark, with M = N_a Hinv N_b' (3x3), Ka = 2[Z_a]x, Kb = 2[Z_b]x:
     //     H_pl,a Hinv H_pl,b' = [ M , -M Kb ; Ka M , -Ka M Kb ]
-    __shared__ double s_stage[kBlock / 64][2][kSchurBatch][kSchurSlot];
+    __shared__ double s_stage[kBlock / 64][2][kSchurBatch][4][kSchurSlot];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int job = blockIdx.x * (kBlock / 64) + wave; // wave-uniform: item records come through the scalar cache
+    const int job = blockIdx.x * (kBlock / 64) + wave;
     if (job >= d.n_jobs) return;
-    const int i = lane >> 3, j = lane & 7;
-    const int it0 = d.job_item0[job], it1 = d.job_item0[job + 1];
-    const bool diag = d.job_diag[job] != 0;
+    const int qt = lane >> 4, i = (lane >> 2) & 3, j = lane & 3;
+    const int it0 = d.qj_begin[4 * job + qt], it1 = d.qj_end[4 * job + qt];
+    const bool diag = d.qj_diag[4 * job + qt] != 0;
+    const int n_pass = d.job_len[job];
     const int4* __restrict__ items = reinterpret_cast<const int4*>(d.it_pack);
     double acc[36], gacc[6];
 #pragma unroll
@@ -746,30 +767,38 @@ __global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
 #pragma unroll
     for (int q = 0; q < 6; ++q) gacc[q] = 0.0;
     const unsigned below_i = (1u << i) - 1u, below_j = (1u << j) - 1u;
+    // three stages in flight: item records of batch k+2, operands of batch k+1 (registers), batch k (LDS) being multiplied
     SchurStage st;
+    int4 pk[kSchurBatch];
     int buf = 0;
-    schur_fetch(d, items, it0, min(kSchurBatch, it1 - it0), diag, lane, st);
-    for (int base = it0; base < it1; base += kSchurBatch, buf ^= 1) {
-        const int nb = min(kSchurBatch, it1 - base);
-        schur_stash(st, nb, lane, s_stage[wave][buf]);
-        const int nbase = base + kSchurBatch;
-        if (nbase < it1) schur_fetch(d, items, nbase, min(kSchurBatch, it1 - nbase), diag, lane, st);
+    schur_fetch_items(items, it0, it1, 0, pk);
+    schur_fetch(d, pk, diag, lane, st);
+    schur_fetch_items(items, it0, it1, kSchurBatch, pk);
+    // The compiler's scheduler otherwise undoes the software pipeline (it moves the loads of the next batch behind
+    // the arithmetic of this one): 267 us instead of 130 us.  The barriers pin the order stash -> issue -> multiply.
+#define SCHUR_PIN __builtin_amdgcn_sched_barrier(0);
+    for (int base = 0; base < n_pass; base += kSchurBatch, buf ^= 1) {
+        schur_stash(st, lane, s_stage[wave][buf]);
+        SCHUR_PIN
+        int mk[kSchurBatch];
+#pragma unroll
+        for (int t = 0; t < kSchurBatch; ++t) mk[t] = st.m[t];
+        if (base + kSchurBatch < n_pass) {
+            schur_fetch(d, pk, diag, lane, st);
+            schur_fetch_items(items, it0, it1, base + 2 * kSchurBatch, pk);
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        int4 pks[kSchurBatch];
-#pragma unroll
-        for (int t = 0; t < kSchurBatch; ++t) pks[t] = items[base + (t < nb ? t : 0)];
+        SCHUR_PIN
 #pragma unroll
         for (int t = 0; t < kSchurBatch; ++t) {
-            if (t >= nb) break;
-            const int4 pk = pks[t];
-            const unsigned mI = (unsigned)pk.w & 0xFFu, mJ = ((unsigned)pk.w >> 8) & 0xFFu;
+            const unsigned mI = (unsigned)mk[t] & 0xFu, mJ = ((unsigned)mk[t] >> 8) & 0xFu;
             const bool active = ((mI >> i) & 1u) && ((mJ >> j) & 1u) && (!diag || i >= j);
             if (!active) continue;
-            const double* slot = s_stage[wave][buf][t];
+            const double* slot = s_stage[wave][buf][t][qt];
             const double* na = slot + 12 * __popc(mI & below_i);
-            const double* nbp = slot + 12 * (diag ? __popc(mJ & below_j) : 8 + __popc(mJ & below_j));
-            const double* Hi = slot + 192;
+            const double* nbp = slot + 12 * (diag ? __popc(mJ & below_j) : 4 + __popc(mJ & below_j));
+            const double* Hi = slot + 96;
             double T[9]; // N_a Hinv
 #pragma unroll
             for (int r = 0; r < 3; ++r) {
@@ -822,23 +851,25 @@ __global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
                 gacc[5] -= -a1 * w0 + a0 * w1;
             }
         }
+        SCHUR_PIN
         // the buffer written two iterations from now is this one: every lane is past its reads by then
         // (wave-synchronous execution, in-order LDS), the barrier below keeps the compiler honest
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
+        SCHUR_PIN
     }
     double* out = d.slab + (size_t)job * 36 * 64;
 #pragma unroll
     for (int q = 0; q < 36; ++q) out[q * 64 + lane] = acc[q];
     if (diag && i == j) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) d.gslab[((size_t)job * 6 + q) * 8 + i] = gacc[q];
+        for (int q = 0; q < 6; ++q) d.gslab[((size_t)(4 * job + qt) * 6 + q) * 4 + i] = gacc[q];
     }
 }
 
 // ---------------------------------------------------------------------------------------------
 // K4b: one workgroup per stored 48 x 48 sub-tile of S: pose terms (H_pp diagonal blocks, odometry
-// blocks) minus the job slabs of this sub-tile, summed in a fixed order, written into its tile.
+// blocks) minus the quarter-job slabs of its four cells, summed in a fixed order, written into its tile.
 // Diagonal sub-tiles also assemble their part of g and the identity padding of the last rows.
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_assemble(BaDev d)
@@ -846,26 +877,28 @@ __global__ __launch_bounds__(kBlock) void k_assemble(BaDev d)
     __shared__ double s_t[48][49];
     const int sub = blockIdx.x, tid = threadIdx.x;
     const int cx = d.sub_cx[sub], cy = d.sub_cy[sub], n = 6 * d.Pf, TS = d.TS;
-    const int j0 = d.sub_job_ptr[sub], j1 = d.sub_job_ptr[sub + 1];
-    // slabs: element e = q*64 + lane  ->  block (i,j) = (lane>>3, lane&7), entry (rr,cc) = (q/6, q%6)
+    // slabs: wave w of this workgroup sums cell (u, v) = (w >> 1, w & 1) of the sub-tile.  A quarter job qj left its
+    // [36][16] values at slab[(qj >> 2)][q][(qj & 3) * 16 + l16]: block (i, j) = (l16 >> 2, l16 & 3), entry (q / 6, q % 6).
     {
-        // 9 elements per thread, all in flight for every job (the jobs are still summed in ascending order)
-        constexpr int NE = 36 * 64 / kBlock;
+        constexpr int NE = 36 * 16 / 64; // 9 elements per lane, all in flight for every quarter job (summed in list order)
+        const int w = tid >> 6, lane = tid & 63, u = w >> 1, vv = w & 1;
+        const int cell = 4 * sub + w;
         double v[NE];
 #pragma unroll
-        for (int u = 0; u < NE; ++u) v[u] = 0.0;
-        for (int jb = j0; jb < j1; ++jb) {
-            const double* sl = d.slab + (size_t)jb * 36 * 64 + tid;
-            double w[NE];
+        for (int k = 0; k < NE; ++k) v[k] = 0.0;
+        for (int x = d.cell_qj_ptr[cell]; x < d.cell_qj_ptr[cell + 1]; ++x) {
+            const int qj = d.cell_qj[x];
+            const double* sl = d.slab + (size_t)(qj >> 2) * 36 * 64 + (qj & 3) * 16;
+            double wv[NE];
 #pragma unroll
-            for (int u = 0; u < NE; ++u) w[u] = sl[u * kBlock];
+            for (int k = 0; k < NE; ++k) { const int e = lane + 64 * k; wv[k] = sl[(e >> 4) * 64 + (e & 15)]; }
 #pragma unroll
-            for (int u = 0; u < NE; ++u) v[u] -= w[u];
+            for (int k = 0; k < NE; ++k) v[k] -= wv[k];
         }
 #pragma unroll
-        for (int u = 0; u < NE; ++u) {
-            const int e = u * kBlock + tid, q = e >> 6, lane = e & 63;
-            s_t[(lane >> 3) * 6 + q / 6][(lane & 7) * 6 + q % 6] = v[u];
+        for (int k = 0; k < NE; ++k) {
+            const int e = lane + 64 * k, q = e >> 4, l16 = e & 15;
+            s_t[(4 * u + (l16 >> 2)) * 6 + q / 6][(4 * vv + (l16 & 3)) * 6 + q % 6] = v[k];
         }
     }
     __syncthreads();
@@ -905,7 +938,9 @@ __global__ __launch_bounds__(kBlock) void k_assemble(BaDev d)
             double v = 0.0;
             if (row < n) {
                 if (d.add_pose_terms) v = d.bp[row];
-                for (int jb = j0; jb < j1; ++jb) v -= d.gslab[((size_t)jb * 6 + r % 6) * 8 + r / 6];
+                const int pl = r / 6, cell = 4 * sub + 3 * (pl >> 2); // diagonal cell (u, u) of the row's pose
+                for (int x = d.cell_qj_ptr[cell]; x < d.cell_qj_ptr[cell + 1]; ++x)
+                    v -= d.gslab[((size_t)d.cell_qj[x] * 6 + r % 6) * 4 + (pl & 3)];
             }
             d.g[row] = v;
         }
