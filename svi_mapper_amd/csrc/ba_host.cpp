@@ -618,7 +618,7 @@ int build_structure(svi_ba* ba)
     const int n_cells = 4 * n_sub;
     int n_cu = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ba->opt.device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
-    const int64_t qj_cap = getenv("SVI_SCHUR_QJ") ? atoi(getenv("SVI_SCHUR_QJ")) : (int64_t)4 * (n_cu * 4);
+    const int64_t qj_cap = (int64_t)4 * (n_cu * 4);
     std::vector<int> cell_count;
     for (int i = 0; i < n_items;) { int j = i; while (j < n_items && items[j].cell == items[i].cell) ++j; cell_count.push_back(j - i); i = j; }
     auto pieces = [&](int len) { int64_t n = 0; for (int c : cell_count) n += (c + len - 1) / len; return n; };
