@@ -134,17 +134,29 @@ struct EdgeIn {
 
 // DIAG: every information matrix of the graph is diagonal (the reference only sets diagonals,
 // Cg2oOptimizer.cpp:1014,1038,1066): 3 planes are stored and the off-diagonal terms fold away at compile time
+// plane access as (uniform base) + (32-bit byte offset of the lane): selects the SGPR-base addressing mode of the
+// global memory instructions, i.e. no 64-bit address arithmetic on the vector ALU per plane
+__device__ __forceinline__ double ldp(const double* __restrict__ base, unsigned byte_off)
+{
+    return *reinterpret_cast<const double*>(reinterpret_cast<const char*>(base) + (size_t)byte_off);
+}
+__device__ __forceinline__ void stp(double* __restrict__ base, unsigned byte_off, double v)
+{
+    *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + (size_t)byte_off) = v;
+}
+
 template <bool DIAG>
 __device__ __forceinline__ void load_edge(const double* __restrict__ zp, const double* __restrict__ ip,
                                           const uint8_t* __restrict__ flags, int E, int e, EdgeIn& in)
 {
-    in.z[0] = zp[e]; in.z[1] = zp[E + e]; in.z[2] = zp[2 * E + e];
+    const unsigned off = (unsigned)e * 8u;
+    in.z[0] = ldp(zp, off); in.z[1] = ldp(zp + (size_t)E, off); in.z[2] = ldp(zp + 2 * (size_t)E, off);
     if (DIAG) {
-        in.info[0] = ip[e]; in.info[3] = ip[E + e]; in.info[5] = ip[2 * E + e];
+        in.info[0] = ldp(ip, off); in.info[3] = ldp(ip + (size_t)E, off); in.info[5] = ldp(ip + 2 * (size_t)E, off);
         in.info[1] = 0.0; in.info[2] = 0.0; in.info[4] = 0.0;
     } else {
 #pragma unroll
-        for (int k = 0; k < 6; ++k) in.info[k] = ip[k * E + e];
+        for (int k = 0; k < 6; ++k) in.info[k] = ldp(ip + (size_t)k * E, off);
     }
     const unsigned f = flags[e];
     in.type = f & kFlagTypeMask;
@@ -238,9 +250,9 @@ __global__ __launch_bounds__(kBlock) void k_linearize_lm(BaDev d, int cur)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) N[3 * r + c] = Cf[3 * r] * R[3 * c] + Cf[3 * r + 1] * R[3 * c + 1] + Cf[3 * r + 2] * R[3 * c + 2];
 #pragma unroll
-            for (int k = 0; k < 9; ++k) d.NZ[(size_t)k * E + e] = lfix ? 0.0 : N[k];
+            for (int k = 0; k < 9; ++k) stp(d.NZ + (size_t)k * E, (unsigned)e * 8u, lfix ? 0.0 : N[k]);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) d.NZ[(size_t)(9 + k) * E + e] = Z[k];
+            for (int k = 0; k < 3; ++k) stp(d.NZ + (size_t)(9 + k) * E, (unsigned)e * 8u, Z[k]);
             // H_ll contribution R N (symmetric, upper 00 01 02 11 12 22) and b_l = -R u
             int k = 0;
 #pragma unroll
@@ -995,14 +1007,15 @@ __global__ __launch_bounds__(kBlock) void k_backsub_chi2(BaDev d, int cur, doubl
             const int r = d.pose_red[s];
             double v[3] = {0.0, 0.0, 0.0};
             if (r >= 0) { // H_pl' dx = N' ( -dt + 2 Z x dq )
-                const double z0 = 2.0 * d.NZ[(size_t)9 * E + e], z1 = 2.0 * d.NZ[(size_t)10 * E + e], z2 = 2.0 * d.NZ[(size_t)11 * E + e];
+                const unsigned eo = (unsigned)e * 8u;
+                const double z0 = 2.0 * ldp(d.NZ + 9 * E, eo), z1 = 2.0 * ldp(d.NZ + 10 * E, eo), z2 = 2.0 * ldp(d.NZ + 11 * E, eo);
                 const double* dxp = d.dx + 6 * r;
                 const double u0 = -dxp[0] + (z1 * dxp[5] - z2 * dxp[4]);
                 const double u1 = -dxp[1] + (z2 * dxp[3] - z0 * dxp[5]);
                 const double u2 = -dxp[2] + (z0 * dxp[4] - z1 * dxp[3]);
 #pragma unroll
                 for (int c = 0; c < 3; ++c)
-                    v[c] = d.NZ[(size_t)c * E + e] * u0 + d.NZ[(size_t)(3 + c) * E + e] * u1 + d.NZ[(size_t)(6 + c) * E + e] * u2;
+                    v[c] = ldp(d.NZ + c * E, eo) * u0 + ldp(d.NZ + (3 + c) * E, eo) * u1 + ldp(d.NZ + (6 + c) * E, eo) * u2;
             }
             s_v[0][tid] = v[0]; s_v[1][tid] = v[1]; s_v[2][tid] = v[2];
         }
