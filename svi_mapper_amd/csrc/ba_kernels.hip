@@ -734,16 +734,15 @@ __device__ __forceinline__ void schur_fetch(const BaDev& d, const int4 (&pk)[kSc
         st.m[t] = pk[t].w;
         const unsigned mI = (unsigned)pk[t].w & 0xFu, mJ = ((unsigned)pk[t].w >> 8) & 0xFu;
         const int nI = __popc(mI), nJ = diag ? 0 : __popc(mJ);
-        // unconditional loads from a clamped edge (edge 0 for an empty slot), the value masked afterwards: no
-        // divergent regions around the loads
+        // unconditional loads from a clamped edge (edge 0 for an empty slot): no divergent regions around the loads,
+        // and no masking either - the multiply only ever reads the slots its masks name
         const bool row = es < 4;
         const bool on = row ? (es < nI) : (es - 4 < nJ);
         const unsigned e = on ? (unsigned)((row ? pk[t].y : pk[t].z - 4) + es) : 0u;
         const double* __restrict__ src = plane0 + e;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) { const double x = src[(size_t)q * E]; st.v[t][q] = on ? x : 0.0; }
-        const double h = d.HinvB[(size_t)12 * (unsigned)pk[t].x + (l16 < 9 ? l16 : 0)];
-        st.hv[t] = (pk[t].w != 0 && l16 < 9) ? h : 0.0;
+        for (int q = 0; q < 6; ++q) st.v[t][q] = src[(size_t)q * E];
+        st.hv[t] = d.HinvB[(size_t)12 * (unsigned)pk[t].x + (l16 < 9 ? l16 : 0)];
     }
 }
 
