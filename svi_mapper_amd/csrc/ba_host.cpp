@@ -912,7 +912,9 @@ int trial(svi_ba* ba, double lambda, bool* failed)
     ba_chi2_aux(d, ba->cur ^ 1, ba->opt.rank, s);
     t.end(s);
     SVI_TRY(reduce_and_read_trial(ba, 12));
-    *failed = ba->h_status[0] != 0;
+    // with several ranks the landmark blocks (and so the status word) are local: a failure anywhere arrives as a
+    // non-finite chi2 through the all-reduce, so every rank takes the same branch of the LM rule
+    *failed = ba->h_status[0] != 0 || (ba->opt.n_ranks > 1 && !std::isfinite(ba->h_scal[0]));
     return SVI_OK;
 }
 

@@ -1109,6 +1109,9 @@ __global__ __launch_bounds__(kRedThreads) void k_reduce_trial(BaDev d, int n_pub
         d.scal[0] = part[0] + d.scal[6];
         d.scal[1] = part[1] + d.scal[7];
         d.scal[2] = part[2];
+        // several ranks: a rank whose own landmark blocks or factorisation failed must fail the trial everywhere -
+        // its chi2 goes out as +inf, which survives the sum of the all-reduce (ba_host.cpp trial())
+        if (n_pub == 0 && *d.chol_status != 0) d.scal[0] = __builtin_inf();
     }
     if (n_pub > 0) {
         __threadfence();

@@ -10,7 +10,7 @@ from svi_mapper_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _run_sharded(svi, prob, n_ranks, iters):
+def _run_sharded(svi, prob, n_ranks, iters, extra=None):
     """n_ranks handles in n_ranks threads of one process; the hook sums their buffers in a fixed order."""
     import torch
     cam = prob["cam"]
@@ -42,10 +42,13 @@ def _run_sharded(svi, prob, n_ranks, iters):
         try:
             ba = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"], rank=rank, n_ranks=n_ranks)
             synth.build_ba_graph(ba, prob)
+            if extra is not None:
+                extra(ba)
             ba.set_allreduce(hook_for(rank))
             ba.initialize()
             done = [ba.optimize(n) for n in iters]
-            out[rank] = (done, ba.get_poses()[1], ba.get_landmarks()[1], ba.chi2(), ba.stats().n_landmarks_local)
+            st = ba.stats()
+            out[rank] = (done, ba.get_poses()[1], ba.get_landmarks()[1], ba.chi2(), st.n_landmarks_local, st.lm_trials, st.chol_failures)
             ba.close()
         except Exception as e:  # noqa: BLE001
             errs.append(e)
@@ -80,6 +83,32 @@ def test_sharded_equals_unsharded(svi, n_ranks):
         assert np.abs(o[1] - T).max() < 1e-9
         assert np.abs(o[2] - p).max() < 1e-9 * max(1.0, np.abs(p).max())  # every rank ends up with ALL landmarks
         assert abs(o[3][0] - ref.chi2()[0]) <= 1e-9 * ref.chi2()[0]
+
+
+def test_failed_trial_is_failed_on_every_rank(svi):
+    """one landmark block is not positive definite until lambda has grown (a prior with negative information): only the
+    rank that owns the landmark sees that in its status word - the failure has to travel with the reduced scalars, or the
+    ranks would take different branches of the LM rule"""
+    prob = synth.make_ba_problem(12, 400, 2600, seed=5)
+    cam = prob["cam"]
+
+    def extra(ba):
+        ba.add_landmark(900000, prob["lm_init"][3], fixed=True)
+        ba.add_edge_lm_lm(3, 900000, np.zeros(3), [-1e4, 0, 0, -1e4, 0, -1e4], robust=False)
+
+    iters = (1, 3)
+    ref = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"])
+    synth.build_ba_graph(ref, prob)
+    extra(ref)
+    ref.initialize()
+    done = [ref.optimize(n) for n in iters]
+    st = ref.stats()
+    assert st.chol_failures > 0, "the graph was supposed to provoke failed trials"
+    out = _run_sharded(svi, prob, 2, iters, extra)
+    for o in out:
+        assert o[0] == done
+        assert o[5] == st.lm_trials and o[6] == st.chol_failures
+        assert np.abs(o[1] - ref.get_poses()[1]).max() < 1e-8
 
 
 def test_missing_hook_fails_loudly(svi):
