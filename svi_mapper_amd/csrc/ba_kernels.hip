@@ -668,31 +668,38 @@ __global__ __launch_bounds__(kRedThreads) void k_lin_post(BaDev d, int n_ranks)
 // ---------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(kBlock) void k_invert_landmarks(BaDev d, double lambda)
 {
-    const int l = blockIdx.x * kBlock + threadIdx.x;
-    if (l >= d.Ll) return;
+    __shared__ double s_rec[kBlock][9]; // odd row stride: conflict-free both ways
+    const int l0 = blockIdx.x * kBlock, tid = threadIdx.x, l = l0 + tid;
     const size_t Ll = d.Ll;
-    double inv[6] = {0, 0, 0, 0, 0, 0};
-    if (!d.lm_fixed[l]) {
-        const double a = d.Hll[l] + lambda, b = d.Hll[Ll + l], c = d.Hll[2 * Ll + l];
-        const double e = d.Hll[3 * Ll + l] + lambda, f = d.Hll[4 * Ll + l], i = d.Hll[5 * Ll + l] + lambda;
-        const double c00 = e * i - f * f, c01 = c * f - b * i, c02 = b * f - c * e;
-        const double det = a * c00 + b * c01 + c * c02;
-        const double m1 = a * e - b * b;
-        if (!(a > 0.0) || !(m1 > 0.0) || !(det > 0.0)) { *d.chol_status = -1; }
-        else {
-            const double id = 1.0 / det;
-            inv[0] = c00 * id; inv[1] = c01 * id; inv[2] = c02 * id;
-            inv[3] = (a * i - c * c) * id; inv[4] = (b * c - a * f) * id; inv[5] = m1 * id;
+    if (l < d.Ll) {
+        double inv[6] = {0, 0, 0, 0, 0, 0};
+        if (!d.lm_fixed[l]) {
+            const double a = d.Hll[l] + lambda, b = d.Hll[Ll + l], c = d.Hll[2 * Ll + l];
+            const double e = d.Hll[3 * Ll + l] + lambda, f = d.Hll[4 * Ll + l], i = d.Hll[5 * Ll + l] + lambda;
+            const double c00 = e * i - f * f, c01 = c * f - b * i, c02 = b * f - c * e;
+            const double det = a * c00 + b * c01 + c * c02;
+            const double m1 = a * e - b * b;
+            if (!(a > 0.0) || !(m1 > 0.0) || !(det > 0.0)) { *d.chol_status = -1; }
+            else {
+                const double id = 1.0 / det;
+                inv[0] = c00 * id; inv[1] = c01 * id; inv[2] = c02 * id;
+                inv[3] = (a * i - c * c) * id; inv[4] = (b * c - a * f) * id; inv[5] = m1 * id;
+            }
         }
+#pragma unroll
+        for (int k = 0; k < 6; ++k) { d.Hinv[(size_t)k * Ll + l] = inv[k]; s_rec[tid][k] = inv[k]; }
+#pragma unroll
+        for (int k = 0; k < 3; ++k) s_rec[tid][6 + k] = d.bl[(size_t)k * Ll + l];
     }
-#pragma unroll
-    for (int k = 0; k < 6; ++k) d.Hinv[(size_t)k * Ll + l] = inv[k];
-    // one contiguous record per landmark for the Schur staging (a single cache line instead of nine planes)
-    double* rec = d.HinvB + (size_t)12 * l;
-#pragma unroll
-    for (int k = 0; k < 6; ++k) rec[k] = inv[k];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) rec[6 + k] = d.bl[(size_t)k * Ll + l];
+    __syncthreads();
+    // one contiguous record per landmark for the Schur staging (a single cache line instead of nine planes),
+    // written out coalesced: the records of this workgroup's landmarks are one contiguous range
+    const int nv = min(kBlock, d.Ll - l0);
+    double* out = d.HinvB + (size_t)12 * l0;
+    for (int i = tid; i < 12 * nv; i += kBlock) {
+        const int r = i / 12, k = i - 12 * r;
+        if (k < 9) out[i] = s_rec[r][k];
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
