@@ -101,6 +101,17 @@ __device__ __forceinline__ v4f64 mfma_block(const double* sA, int ra, const doub
     return acc;
 }
 
+template <int KK, int LD>
+__device__ __forceinline__ v4f64 mfma_block_acc(const double* sA, int ra, const double* sB, int rb, v4f64 acc)
+{
+    const int lane = threadIdx.x & 63;
+    const double* pa = sA + (ra + (lane & 15)) * LD + (lane >> 4);
+    const double* pb = sB + (rb + (lane & 15)) * LD + (lane >> 4);
+#pragma unroll 6
+    for (int k0 = 0; k0 < KK; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0], acc, 0, 0, 0);
+    return acc;
+}
+
 // 1/x to full double precision from the hardware seed (two Newton steps), no IEEE division sequence
 __device__ __forceinline__ double fast_rcp(double x)
 {
@@ -154,29 +165,60 @@ __device__ __forceinline__ bool potrf_sweep(const double* __restrict__ A, double
     TileRegs<TS> pre;
     double ypre = 0.0;
     if (npre > 0) { tile_load<TS>(Lt + (size_t)pre_tile[0] * TS * TS, pre); if (tid < TS) ypre = y[pre_col[0] * TS + tid]; }
+    // A L(k,q)' L(k,q) products are MFMA work: the 16x16 blocks of the lower triangle go round the eight waves, the
+    // accumulators run over all sources, the sum lands in the (still unused) X image and is subtracted from the
+    // register-resident tile once.
+    constexpr int NBLK = NB * (NB + 1) / 2, NWV = kPotrfThreads / 64, PER = (NBLK + NWV - 1) / NWV;
+    const int wave = tid >> 6, lane = tid & 63;
+    v4f64 accU[PER];
+#pragma unroll
+    for (int u = 0; u < PER; ++u) accU[u] = {0.0, 0.0, 0.0, 0.0};
     for (int w = 0; w < npre; ++w) {
         tile_store<TS>(pre, sL);
         if (tid < TS) s_rs[tid] = ypre;
         __syncthreads();
         // the next source tile travels while this one is applied
         if (w + 1 < npre) { tile_load<TS>(Lt + (size_t)pre_tile[w + 1] * TS * TS, pre); if (tid < TS) ypre = y[pre_col[w + 1] * TS + tid]; }
-        for (int m = 0; m < TS; m += 2) {
-            double2 rr[NI > 0 ? NI : 1], cc[NB];
 #pragma unroll
-            for (int i = 0; i < NI; ++i) rr[i] = *reinterpret_cast<const double2*>(sL + (16 * (2 * i + H) + ty) * LD + m);
-#pragma unroll
-            for (int b = 0; b < NB; ++b) cc[b] = *reinterpret_cast<const double2*>(sL + (16 * b + tx) * LD + m);
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-#pragma unroll
-                for (int b = 0; b <= 2 * i + H; ++b) e[i][b] = fma(-rr[i].y, cc[b].y, fma(-rr[i].x, cc[b].x, e[i][b]));
+        for (int u = 0; u < PER; ++u) {
+            const int bi = wave + NWV * u;
+            if (bi < NBLK) {
+                int a = 0;
+                while ((a + 1) * (a + 2) / 2 <= bi) ++a;
+                const int b = bi - a * (a + 1) / 2;
+                accU[u] = mfma_block_acc<TS, LD>(sL, 16 * a, sL, 16 * b, accU[u]);
+            }
         }
-        if (tid < TS) {
-            double acc = 0.0;
-#pragma unroll 8
-            for (int m = 0; m < TS; ++m) acc = fma(sL[tid * LD + m], s_rs[m], acc);
-            s_g[tid] -= acc;
+        if (tid < TS) { // four partial sums: a single chain of TS dependent FP64 FMAs (36 cycles each) would cost 1.4 us
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 6
+            for (int m = 0; m < TS; m += 4) {
+                a0 = fma(sL[tid * LD + m], s_rs[m], a0);
+                a1 = fma(sL[tid * LD + m + 1], s_rs[m + 1], a1);
+                a2 = fma(sL[tid * LD + m + 2], s_rs[m + 2], a2);
+                a3 = fma(sL[tid * LD + m + 3], s_rs[m + 3], a3);
+            }
+            s_g[tid] -= (a0 + a1) + (a2 + a3);
         }
+        __syncthreads();
+    }
+    if (npre > 0) {
+#pragma unroll
+        for (int u = 0; u < PER; ++u) {
+            const int bi = wave + NWV * u;
+            if (bi < NBLK) {
+                int a = 0;
+                while ((a + 1) * (a + 2) / 2 <= bi) ++a;
+                const int b = bi - a * (a + 1) / 2;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) sX[(16 * a + (lane >> 4) + 4 * q) * LD + 16 * b + (lane & 15)] = accU[u][q];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+#pragma unroll
+            for (int b = 0; b <= 2 * i + H; ++b) e[i][b] -= sX[(16 * (2 * i + H) + ty) * LD + 16 * b + tx];
         __syncthreads();
     }
     if (stop_after == 5) { if (tid < TS) y[k * TS + tid] = e[0][0]; return true; }
@@ -411,10 +453,15 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
     }
     // y_k = L_kk^-1 g_k (g_k is final: every earlier column has already subtracted its part)
     if (tid < TS) {
-        double acc = 0.0;
-#pragma unroll 8
-        for (int c = 0; c < TS; ++c) acc = fma(sX[tid * LD + c], s_g[c], acc); // X is zero above the diagonal
-        y[k * TS + tid] = acc;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0; // X is zero above the diagonal; four partial sums (latency)
+#pragma unroll 6
+        for (int c = 0; c < TS; c += 4) {
+            a0 = fma(sX[tid * LD + c], s_g[c], a0);
+            a1 = fma(sX[tid * LD + c + 1], s_g[c + 1], a1);
+            a2 = fma(sX[tid * LD + c + 2], s_g[c + 2], a2);
+            a3 = fma(sX[tid * LD + c + 3], s_g[c + 3], a3);
+        }
+        y[k * TS + tid] = (a0 + a1) + (a2 + a3);
     }
 }
 
@@ -456,16 +503,6 @@ __global__ __launch_bounds__(kBlock) void k_trsm(const double* __restrict__ S, d
 // Runs in the extra workgroups (512 threads) of the level kernel; the 9 16x16 sub-blocks stay in the MFMA
 // accumulators across the sources, the tile is read-modified-written once.
 // ---------------------------------------------------------------------------------------------
-template <int KK, int LD>
-__device__ __forceinline__ v4f64 mfma_block_acc(const double* sA, int ra, const double* sB, int rb, v4f64 acc)
-{
-    const int lane = threadIdx.x & 63;
-    const double* pa = sA + (ra + (lane & 15)) * LD + (lane >> 4);
-    const double* pb = sB + (rb + (lane & 15)) * LD + (lane >> 4);
-#pragma unroll 6
-    for (int k0 = 0; k0 < KK; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0], acc, 0, 0, 0);
-    return acc;
-}
 
 template <int TS>
 __device__ void gemm_target_block(double* __restrict__ S, const double* __restrict__ Lt, const StepArgs& sa, int work, double* __restrict__ g,
@@ -482,19 +519,48 @@ __device__ void gemm_target_block(double* __restrict__ S, const double* __restri
     v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
     double gacc = 0.0;
     const bool g_thread = row >= 0 && qc == 0 && threadIdx.x >= 64 && threadIdx.x < 64 + kOB;
+    // the operand rows of source q+1 travel (in registers) while source q is multiplied out of LDS
+    constexpr int N2 = kOB * TS / 2, IT = (N2 + kPotrfThreads - 1) / kPotrfThreads;
+    double2 ra[IT], rb[IT];
+    auto fetch = [&](int q) {
+        const double2* pa = reinterpret_cast<const double2*>(Lt + (size_t)sa.pair_a[q] * TS * TS + (size_t)kOB * qr * TS);
+        const double2* pb = reinterpret_cast<const double2*>(Lt + (size_t)sa.pair_b[q] * TS * TS + (size_t)kOB * qc * TS);
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = it * kPotrfThreads + (int)threadIdx.x;
+            if (N2 % kPotrfThreads == 0 || i < N2) { ra[it] = pa[i]; rb[it] = pb[i]; }
+        }
+    };
+    auto park = [&]() {
+#pragma unroll
+        for (int it = 0; it < IT; ++it) {
+            const int i = it * kPotrfThreads + (int)threadIdx.x;
+            if (N2 % kPotrfThreads == 0 || i < N2) {
+                const int r = i / (TS / 2), c = 2 * (i % (TS / 2));
+                sA[r * LD + c] = ra[it].x; sA[r * LD + c + 1] = ra[it].y;
+                sB[r * LD + c] = rb[it].x; sB[r * LD + c + 1] = rb[it].y;
+            }
+        }
+    };
+    if (p0 < p1) fetch(p0);
     for (int q = p0; q < p1; ++q) {
-        rows_to_lds<TS, kOB, kPotrfThreads>(Lt + (size_t)sa.pair_a[q] * TS * TS, kOB * qr, sA);
-        rows_to_lds<TS, kOB, kPotrfThreads>(Lt + (size_t)sa.pair_b[q] * TS * TS, kOB * qc, sB);
+        park();
         __syncthreads();
+        if (q + 1 < p1) fetch(q + 1);
         acc0 = mfma_block_acc<TS, LD>(sA, (st0 / 3) * 16, sB, (st0 % 3) * 16, acc0);
         if (st1 < 9) acc1 = mfma_block_acc<TS, LD>(sA, (st1 / 3) * 16, sB, (st1 % 3) * 16, acc1);
-        if (g_thread) { // forward substitution rides along: g_i -= L_iq y_q
+        if (g_thread) { // forward substitution rides along: g_i -= L_iq y_q  (four partial sums: the chain is latency-bound)
             const int r = threadIdx.x - 64;
             const double* yq = y + sa.pair_src[q] * TS;
-            double a = 0.0;
-#pragma unroll 8
-            for (int m = 0; m < TS; ++m) a = fma(sA[r * LD + m], yq[m], a);
-            gacc += a;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 6
+            for (int m = 0; m < TS; m += 4) {
+                a0 = fma(sA[r * LD + m], yq[m], a0);
+                a1 = fma(sA[r * LD + m + 1], yq[m + 1], a1);
+                a2 = fma(sA[r * LD + m + 2], yq[m + 2], a2);
+                a3 = fma(sA[r * LD + m + 3], yq[m + 3], a3);
+            }
+            gacc += (a0 + a1) + (a2 + a3);
         }
         __syncthreads();
     }
@@ -545,7 +611,7 @@ __global__ __launch_bounds__(kPotrfThreads) void k_back_solve(const double* __re
     if (failed != 0) return;
     // (1) sum_{i>k} L_ik' x_i : the sub-diagonal tiles of the column are spread over the waves, lane = column of the
     //     tile (and column + 64), rows streamed with the x_i entry broadcast from LDS
-    double a0 = 0.0, a1 = 0.0;
+    double a0 = 0.0, a1 = 0.0, a0b = 0.0, a1b = 0.0;
     constexpr int RB = 24, NRB = TS / RB; // a work unit = RB rows of one tile; units go round the waves
     static_assert(TS % RB == 0 && RB % 8 == 0, "tile edge");
     for (int u = wave; u < nq * NRB; u += NW) {
@@ -563,15 +629,15 @@ __global__ __launch_bounds__(kPotrfThreads) void k_back_solve(const double* __re
 #pragma unroll
             for (int w = 0; w < 8; ++w) { v0[w] = L[(r8 + w) * TS + c0]; if (TS > 64) v1[w] = L[(r8 + w) * TS + c1]; }
 #pragma unroll
-            for (int w = 0; w < 8; ++w) {
-                const double xr = s_x[wave][r8 + w];
-                a0 = fma(v0[w], xr, a0);
-                if (TS > 64) a1 = fma(v1[w], xr, a1);
+            for (int w = 0; w < 8; w += 2) { // two chains per column: the FMAs are latency-bound
+                const double xr = s_x[wave][r8 + w], xs = s_x[wave][r8 + w + 1];
+                a0 = fma(v0[w], xr, a0); a0b = fma(v0[w + 1], xs, a0b);
+                if (TS > 64) { a1 = fma(v1[w], xr, a1); a1b = fma(v1[w + 1], xs, a1b); }
             }
         }
     }
-    if (lane < TS) s_part[wave][lane] = a0;
-    if (lane + 64 < TS) s_part[wave][lane + 64] = a1;
+    if (lane < TS) s_part[wave][lane] = a0 + a0b;
+    if (lane + 64 < TS) s_part[wave][lane + 64] = a1 + a1b;
     __syncthreads();
     if (tid < TS) {
         double sum = 0.0;
@@ -581,16 +647,16 @@ __global__ __launch_bounds__(kPotrfThreads) void k_back_solve(const double* __re
     }
     __syncthreads();
     // (2) x_k = Linv_kk' s_acc (Linv is lower triangular): rows split over the waves
-    double b0 = 0.0, b1 = 0.0;
+    double b0[2] = {0.0, 0.0}, b1[2] = {0.0, 0.0};
 #pragma unroll
     for (int rr = 0; rr < RW; ++rr) {
         const int r = wave * RW + rr;
         const double sr = r < TS ? s_acc[r < TS ? r : 0] : 0.0;
-        b0 = fma(r >= c0 ? xv0[rr] : 0.0, sr, b0);   // Linv is lower triangular
-        if (TS > 64) b1 = fma(r >= c1 ? xv1[rr] : 0.0, sr, b1);
+        b0[rr & 1] = fma(r >= c0 ? xv0[rr] : 0.0, sr, b0[rr & 1]);   // Linv is lower triangular
+        if (TS > 64) b1[rr & 1] = fma(r >= c1 ? xv1[rr] : 0.0, sr, b1[rr & 1]);
     }
-    if (lane < TS) s_part[wave][lane] = b0;
-    if (lane + 64 < TS) s_part[wave][lane + 64] = b1;
+    if (lane < TS) s_part[wave][lane] = b0[0] + b0[1];
+    if (lane + 64 < TS) s_part[wave][lane + 64] = b1[0] + b1[1];
     __syncthreads();
     if (tid < TS) {
         double sum = 0.0;

@@ -548,6 +548,15 @@ int build_structure(svi_ba* ba)
         }
     }
     h_trsm_ptr[n_steps] = (int)st_tile.size();
+    if (getenv("SVI_DEBUG_PLAN")) {
+        for (int st = 0; st < n_steps; ++st) {
+            int mxpre = 0, mxpair = 0;
+            for (int q = h_step_ptr[st]; q < h_step_ptr[st + 1]; ++q) mxpre = std::max(mxpre, pre_ptr[step_col[q] + 1] - pre_ptr[step_col[q]]);
+            for (int t = h_tgt_ptr[st]; t < h_tgt_ptr[st + 1]; ++t) mxpair = std::max(mxpair, tgt_pair_ptr[t + 1] - tgt_pair_ptr[t]);
+            fprintf(stderr, "level %d: %d columns, max pre sources %d, %d update targets, max pairs per target %d, %d trsm tiles\n", st,
+                    h_step_ptr[st + 1] - h_step_ptr[st], mxpre, h_tgt_ptr[st + 1] - h_tgt_ptr[st], mxpair, h_trsm_ptr[st + 1] - h_trsm_ptr[st]);
+        }
+    }
 
     // ---- Schur decomposition: always on 48 x 48 sub-tiles (8 poses x 8 poses), whatever TS is ----
     // item  = (landmark, row chunk cX, column chunk cY): the poses of the landmark in either chunk as
