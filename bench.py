@@ -327,7 +327,8 @@ def main():
     run_exact(bap, args.steps)
     phases = bap.phase_times()
     st = bap.stats()
-    bap.time_sweep(50)               # warm-up (clocks, caches) - untimed
+    bap.time_sweep(1000)             # warm-up, untimed: ~45 ms of back-to-back sweeps so that the clocks have ramped up after the
+                                     # (mostly idle, fully synchronised) profiled run above
     sweep_ms = bap.time_sweep(200)  # HIP events around 200 back-to-back sweeps (K2 then K3) on the library's stream
     sweep_parts = (bap.time_sweep(200, 1), bap.time_sweep(200, 2))
     bap.close()
