@@ -15,6 +15,7 @@
 
 #include <algorithm>
 #include <cfloat>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -133,14 +134,18 @@ int allreduce(svi_ba* ba, double* buf, size_t count)
 // ---------------------------------------------------------------------------------------------
 // structure analysis (g2o initializeOptimization + buildStructure equivalent)
 // ---------------------------------------------------------------------------------------------
+#define SVI_TIMING_MARK(k) do { if (dbg_t) { auto now_ = std::chrono::steady_clock::now(); fprintf(stderr, "build_structure: section %d starts at %.1f ms\n", k, std::chrono::duration<double, std::milli>(now_ - t_begin_).count()); } } while (0)
 int build_structure(svi_ba* ba)
 {
+    const bool dbg_t = getenv("SVI_DEBUG_PLAN") != nullptr;
+    const auto t_begin_ = std::chrono::steady_clock::now();
     BaDev& d = ba->d;
     const svi_ba_options& o = ba->opt;
     d.fx = o.fx; d.fy = o.fy; d.cx = o.cx; d.cy = o.cy; d.cauchy_delta = o.cauchy_delta;
     const int Pn = (int)ba->poses.size();
     const int Ltot = (int)ba->lms.size();
 
+    SVI_TIMING_MARK(0);
     // ---- vertex order: ascending id (g2o index mapping) ----
     ba->pose_order.resize(Pn);
     std::iota(ba->pose_order.begin(), ba->pose_order.end(), 0);
@@ -152,6 +157,7 @@ int build_structure(svi_ba* ba)
         else { pose_red[s] = (int)red_slot.size(); red_slot.push_back(s); }
     }
     const int Pf = (int)red_slot.size();
+    SVI_TIMING_MARK(1);
     // ---- elimination order of the reduced camera system (nested dissection of the key-frame sequence) ----
     // The reduced system of a trajectory is block-banded: in natural order its Cholesky is ONE chain of tile
     // columns.  Cutting the sequence at separators as wide as the co-visibility span gives independent chains
@@ -255,6 +261,7 @@ int build_structure(svi_ba* ba)
     std::vector<int> lm_slot(Ltot);
     for (int s = 0; s < Ltot; ++s) lm_slot[ba->lm_order[s]] = s;
 
+    SVI_TIMING_MARK(2);
     // ---- landmark sharding: contiguous slot ranges balanced by projection-edge count ----
     std::vector<int64_t> deg(Ltot + 1, 0);
     for (const HProj& e : ba->proj) deg[lm_slot[e.lm] + 1]++;
@@ -272,6 +279,7 @@ int build_structure(svi_ba* ba)
     ba->L1 = bound(o.rank + 1);
     const int L0 = ba->L0, Ll = ba->L1 - ba->L0;
 
+    SVI_TIMING_MARK(3);
     // ---- local projection edges, lm-major: (landmark, reduced pose [fixed first], slot) ----
     std::vector<int> loc;
     loc.reserve(ba->proj.size());
@@ -280,15 +288,23 @@ int build_structure(svi_ba* ba)
         if (s >= L0 && s < ba->L1) loc.push_back(i);
     }
     const int E = (int)loc.size();
-    std::sort(loc.begin(), loc.end(), [&](int a, int b) {
-        const HProj &x = ba->proj[a], &y = ba->proj[b];
-        const int lx = lm_slot[x.lm], ly = lm_slot[y.lm];
-        if (lx != ly) return lx < ly;
-        const int rx = pose_red[pose_slot[x.pose]], ry = pose_red[pose_slot[y.pose]];
-        if (rx != ry) return rx < ry;
-        if (pose_slot[x.pose] != pose_slot[y.pose]) return pose_slot[x.pose] < pose_slot[y.pose];
-        return a < b;
-    });
+    {
+        // order: landmark slot, then reduced pose index (fixed poses first), then pose slot, then insertion order -
+        // two stable counting sorts (by pose rank, then by landmark) instead of a comparison sort over 800 k records
+        std::vector<int> prank(Pn), pidx(Pn);
+        for (int s = 0; s < Pn; ++s) pidx[s] = s;
+        std::sort(pidx.begin(), pidx.end(), [&](int a, int b) { return pose_red[a] != pose_red[b] ? pose_red[a] < pose_red[b] : a < b; });
+        for (int r = 0; r < Pn; ++r) prank[pidx[r]] = r;
+        auto counting_sort = [](std::vector<int>& v, int n_keys, auto&& key) {
+            std::vector<int> cnt(n_keys + 1, 0), out(v.size());
+            for (int x : v) cnt[key(x) + 1]++;
+            for (int k = 0; k < n_keys; ++k) cnt[k + 1] += cnt[k];
+            for (int x : v) out[cnt[key(x)]++] = x;
+            v.swap(out);
+        };
+        counting_sort(loc, Pn, [&](int i) { return prank[pose_slot[ba->proj[i].pose]]; });
+        counting_sort(loc, ba->L1 - L0, [&](int i) { return lm_slot[ba->proj[i].lm] - L0; });
+    }
     bool diag_info = true;
     for (const HProj& e : ba->proj) if (e.info[1] != 0.0 || e.info[2] != 0.0 || e.info[4] != 0.0) { diag_info = false; break; }
     const int planes = diag_info ? 3 : 6;
@@ -323,11 +339,18 @@ int build_structure(svi_ba* ba)
     std::vector<uint8_t> lm_fixed(Ll);
     for (int l = 0; l < Ll; ++l) lm_fixed[l] = (uint8_t)(ba->lms[ba->lm_order[L0 + l]].fixed ? 1 : 0);
 
+    SVI_TIMING_MARK(4);
     // ---- pose-major copy: free poses only, (slot, landmark) ----
     std::vector<int> pm;
     pm.reserve(E);
     for (int k = 0; k < E; ++k) if (pose_red[e_pose[k]] >= 0) pm.push_back(k);
-    std::stable_sort(pm.begin(), pm.end(), [&](int a, int b) { return e_pose[a] < e_pose[b]; });
+    { // stable counting sort by pose slot
+        std::vector<int> cnt(Pn + 1, 0), out(pm.size());
+        for (int x : pm) cnt[e_pose[x] + 1]++;
+        for (int k = 0; k < Pn; ++k) cnt[k + 1] += cnt[k];
+        for (int x : pm) out[cnt[e_pose[x]]++] = x;
+        pm.swap(out);
+    }
     const int Epm = (int)pm.size();
     std::vector<int> pm_lm(Epm), chunk_pose, chunk_begin, pose_chunk_ptr(Pn + 1, 0);
     std::vector<uint8_t> pm_flags(Epm);
@@ -356,6 +379,7 @@ int build_structure(svi_ba* ba)
     // chunks are contiguous: the next chunk (same or next pose) starts exactly where this one ends,
     // so chunk_begin[c+1] is the end of chunk c
 
+    SVI_TIMING_MARK(5);
     // ---- pose-only / landmark-only edges ----
     std::vector<int> se3_i, se3_j, acc_pose, ll_free;
     std::vector<double> se3_Z, se3_info, acc_a, acc_info, ll_ref, ll_z, ll_info;
@@ -420,6 +444,7 @@ int build_structure(svi_ba* ba)
     for (int f : ll_free) lm_ll_ptr[f + 1]++;
     for (int l = 0; l < Ll; ++l) lm_ll_ptr[l + 1] += lm_ll_ptr[l];
 
+    SVI_TIMING_MARK(6);
     // ---- reduced system tiling (identical on every rank: derived from the GLOBAL graph) ----
     int TS = o.chol_tile > 0 ? o.chol_tile : 96;
     if (TS % 48 != 0 || TS > kMaxTile) return fail(SVI_ERR_INVALID, "chol_tile must be 48 or 96");
@@ -558,6 +583,7 @@ int build_structure(svi_ba* ba)
         }
     }
 
+    SVI_TIMING_MARK(7);
     // ---- Schur decomposition: always on 48 x 48 sub-tiles (8 poses x 8 poses), whatever TS is ----
     // item  = (landmark, row chunk cX, column chunk cY): the poses of the landmark in either chunk as
     //         8-bit masks plus the first lm-major edge of each segment
@@ -591,14 +617,16 @@ int build_structure(svi_ba* ba)
     constexpr int PQ = 4;
     struct Item { int cell, lm, a0, b0, masks; };
     std::vector<Item> items;
+    items.reserve((size_t)E * 2);
+    struct Seg { int chunk, begin, mask, count; };
+    std::vector<Seg> seg;
     int64_t total_pairs = 0;
     for (int l = 0; l < Ll; ++l) {
         if (lm_fixed[l]) continue;
         int a = lm_ptr[l];
         const int end = lm_ptr[l + 1];
         while (a < end && pose_red[e_pose[a]] < 0) ++a; // edges to fixed poses come first
-        struct Seg { int chunk, begin, mask, count; };
-        std::vector<Seg> seg;
+        seg.clear();
         while (a < end) {
             const int c = pose_red[e_pose[a]] / PQ;
             Seg sg{c, a, 0, 0};
@@ -615,7 +643,14 @@ int build_structure(svi_ba* ba)
                 total_pairs += (x == y) ? (int64_t)seg[x].count * (seg[x].count + 1) / 2 : (int64_t)seg[x].count * seg[y].count;
             }
     }
-    std::stable_sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.cell < b.cell; });
+    { // stable counting sort by cell
+        std::vector<int> cnt(4 * n_sub + 1, 0);
+        std::vector<Item> out(items.size());
+        for (const Item& it : items) cnt[it.cell + 1]++;
+        for (int c = 0; c < 4 * n_sub; ++c) cnt[c + 1] += cnt[c];
+        for (const Item& it : items) out[cnt[it.cell]++] = it;
+        items.swap(out);
+    }
     const int n_items = (int)items.size();
     std::vector<int> it_pack((size_t)4 * std::max(n_items, 1));
     for (int i = 0; i < n_items; ++i) {
@@ -683,6 +718,7 @@ int build_structure(svi_ba* ba)
     }
     sub_aux_ptr[n_sub] = (int)sub_aux_ref.size();
 
+    SVI_TIMING_MARK(8);
     // ---- upload ----
     d.Pn = Pn; d.Pf = Pf; d.Ll = Ll; d.E = E;
     d.n_lm_blocks = n_lm_blocks; d.n_chunks = n_chunks;
@@ -818,6 +854,7 @@ int build_structure(svi_ba* ba)
     st.chol_n = n; st.chol_tile = TS; st.chol_tiles_nnz = n_tiles; st.chol_steps = n_steps;
     st.reduce_doubles = d.red_count;
     st.chol_flops = chol_flops;
+    SVI_TIMING_MARK(9);
     return SVI_OK;
 }
 
