@@ -209,17 +209,35 @@ int build_structure(svi_ba* ba)
                 for (auto& pc : pieces) for (int r = pc.first; r < pc.second; ++r) perm[r] = pos++;
                 return true;
             };
+            // which free poses share a landmark (lower triangle, natural reduced indices): computed once, every
+            // candidate order only re-maps it to tiles
+            const bool use_cpl = Pf <= 4096; // 16 MB at most; longer sequences walk the landmarks per candidate
+            std::vector<uint8_t> cpl(use_cpl ? (size_t)Pf * Pf : 0, 0);
+            if (use_cpl)
+                for (auto& lr : lm_red)
+                    for (size_t x = 0; x < lr.size(); ++x)
+                        for (size_t y = 0; y < lr.size(); ++y)
+                            if (lr[y] <= lr[x]) cpl[(size_t)lr[x] * Pf + lr[y]] = 1;
             // dependency levels (= launches on the critical path) and filled tiles of an order
             auto analyse = [&](const std::vector<int>& perm, int& depth, int& tiles) {
                 std::vector<uint8_t> z((size_t)NTo * NTo, 0);
                 for (int t = 0; t < NTo; ++t) z[(size_t)t * NTo + t] = 1;
-                std::vector<int> v;
-                for (auto& lr : lm_red) {
-                    v.clear();
-                    for (int r : lr) v.push_back(perm[r] / PBo);
-                    std::sort(v.begin(), v.end());
-                    v.erase(std::unique(v.begin(), v.end()), v.end());
-                    for (size_t x = 0; x < v.size(); ++x) for (size_t y = 0; y <= x; ++y) z[(size_t)v[x] * NTo + v[y]] = 1;
+                if (use_cpl) {
+                    for (int ri = 0; ri < Pf; ++ri) { // pose-level coupling mapped to tiles
+                        const int tx = perm[ri] / PBo;
+                        const uint8_t* row = &cpl[(size_t)ri * Pf];
+                        for (int rj = 0; rj <= ri; ++rj)
+                            if (row[rj]) { const int ty = perm[rj] / PBo; z[(size_t)std::max(tx, ty) * NTo + std::min(tx, ty)] = 1; }
+                    }
+                } else {
+                    std::vector<int> v;
+                    for (auto& lr : lm_red) {
+                        v.clear();
+                        for (int r : lr) v.push_back(perm[r] / PBo);
+                        std::sort(v.begin(), v.end());
+                        v.erase(std::unique(v.begin(), v.end()), v.end());
+                        for (size_t x = 0; x < v.size(); ++x) for (size_t y = 0; y <= x; ++y) z[(size_t)v[x] * NTo + v[y]] = 1;
+                    }
                 }
                 for (auto& e : pp) { const int x = perm[e.first] / PBo, y = perm[e.second] / PBo; z[(size_t)std::max(x, y) * NTo + std::min(x, y)] = 1; }
                 std::vector<int> rows;
