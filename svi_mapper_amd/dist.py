@@ -38,6 +38,8 @@ def make_allreduce_hook(group=None):
     import torch.distributed as dist
 
     cache = {}
+    streams = {}
+    gloo = dist.get_backend(group) == "gloo"
 
     def hook(ptr, count, stream):
         key = (ptr, count)
@@ -45,8 +47,10 @@ def make_allreduce_hook(group=None):
         if t is None:
             t = torch.as_tensor(_DevPtr(ptr, count), device=torch.device("cuda", torch.cuda.current_device()))
             cache[key] = t
-        ext = torch.cuda.ExternalStream(stream)
-        if dist.get_backend(group) == "gloo":
+        ext = streams.get(stream)
+        if ext is None:
+            ext = streams[stream] = torch.cuda.ExternalStream(stream)
+        if gloo:
             # rehearsal path (several ranks sharing one GPU, or no RCCL): through the host, synchronously
             ext.synchronize()
             host = t.cpu()
