@@ -130,46 +130,53 @@ __device__ __forceinline__ double fast_rsqrt(double x)
     return r;
 }
 
-// ---------------------------------------------------------------------------------------------
-// potrf + inverse + y_k of one diagonal tile, 512 threads (two waves per SIMD: one wave alone issues
-// an FP64 op only every 8 cycles).  The 16x16 blocks (a,b), b <= a, of the lower triangle are split
-// between the two halves of the workgroup by the parity of a; thread (ty,tx) of half H keeps
-// A[16a+ty][16b+tx] in registers for the whole factorisation.  The right-looking sweep eliminates
-// FOUR columns per barrier: the 4x4 pivot block is factorised redundantly by every lane.
-// ---------------------------------------------------------------------------------------------
 constexpr int kPotrfThreads = 512;
 
-template <int TS, int H>
-__device__ __forceinline__ bool potrf_sweep(const double* __restrict__ A, double* __restrict__ Lg, double* sL, double* sX,
-                                            double (*s_col)[4][TS], double* s_rs, int k, int n, double lambda, int stop_after,
-                                            double* __restrict__ y, const double* __restrict__ Lt, const int* __restrict__ pre_tile,
-                                            const int* __restrict__ pre_col, int npre, double* s_g)
+// ---------------------------------------------------------------------------------------------
+// potrf + inverse + y_k of one diagonal tile, 512 threads.  The right-looking sweep eliminates FOUR columns per
+// barrier (the 4x4 pivot block is factorised redundantly by every lane) and keeps the tile in MFMA accumulator
+// layout: the 16x16 blocks of the lower triangle go round the eight waves (block bi = wave + 8 u), a lane holds rows
+// (lane>>4) + 4q, column lane&15 of its blocks.  The
+// rank-4 trailing update of a quad is then ONE v_mfma_f64_16x16x4 per block (operands: the eliminated panel entries
+// of the block's rows and columns, solved per lane from the published columns), the pending updates of the level
+// below accumulate into the same registers, and nothing is computed 16 times over.  Columns <= the pivot are kept
+// out of an update by zeroing the operand, so an accumulator column always ends as the unscaled factor column.
+// ---------------------------------------------------------------------------------------------
+template <int TS>
+__device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, double* __restrict__ Lg, double* sL, double* sX,
+                                                 double (*s_col)[4][TS], double* s_rs, int k, int n, double lambda, int stop_after,
+                                                 double* __restrict__ y, const double* __restrict__ Lt, const int* __restrict__ pre_tile,
+                                                 const int* __restrict__ pre_col, int npre, double* s_g)
 {
     constexpr int NB = TS / 16, LD = Lds<TS>::LD, KB = 4;
-    constexpr int NI = (NB - H + 1) / 2; // blocks rows a = H, H+2, ... owned by this half
-    const int tid = threadIdx.x, ty = (tid >> 4) & 15, tx = tid & 15;
-    double e[NI > 0 ? NI : 1][NB];
+    constexpr int NBLK = NB * (NB + 1) / 2, NWV = kPotrfThreads / 64, PER = (NBLK + NWV - 1) / NWV;
+    static_assert(kPotrfThreads == 512, "TileRegs assumes 512 threads");
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ln = lane & 15, lk = lane >> 4;
+    int ba[PER], bb[PER];
+    bool own[PER];
+    v4f64 acc[PER];
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int u = 0; u < PER; ++u) {
+        const int bi = wave + NWV * u;
+        own[u] = bi < NBLK;
+        int a = 0;
+        while ((a + 1) * (a + 2) / 2 <= bi) ++a;
+        ba[u] = own[u] ? a : 0;
+        bb[u] = own[u] ? bi - a * (a + 1) / 2 : 0;
 #pragma unroll
-        for (int b = 0; b <= 2 * i + H; ++b) {
-            const int r = 16 * (2 * i + H) + ty, c = 16 * b + tx;
-            double v = A[r * TS + c];
-            if (r == c && k * TS + r < n) v += lambda; // g2o setLambda: H_jj += lambda on real rows
-            e[i][b] = v;
+        for (int q = 0; q < 4; ++q) {
+            const int r = 16 * ba[u] + lk + 4 * q, c = 16 * bb[u] + ln;
+            double v = own[u] ? A[r * TS + c] : 0.0;
+            if (own[u] && r == c && k * TS + r < n) v += lambda; // g2o setLambda: H_jj += lambda on real rows
+            acc[u][q] = v;
         }
+    }
     // pending updates of this tile from the columns of the level just below: A -= L(k,q) L(k,q)' and the forward
     // substitution g_k -= L(k,q) y_q, done here so the critical path is one launch per level.  L(k,q) is staged in
-    // the (still unused) L image, y_q in s_rs; both halves of the workgroup run the same barriers.
-    static_assert(kPotrfThreads == 512, "TileRegs assumes 512 threads");
+    // the (still unused) L image, y_q in s_rs.
     TileRegs<TS> pre;
     double ypre = 0.0;
     if (npre > 0) { tile_load<TS>(Lt + (size_t)pre_tile[0] * TS * TS, pre); if (tid < TS) ypre = y[pre_col[0] * TS + tid]; }
-    // A L(k,q)' L(k,q) products are MFMA work: the 16x16 blocks of the lower triangle go round the eight waves, the
-    // accumulators run over all sources, the sum lands in the (still unused) X image and is subtracted from the
-    // register-resident tile once.
-    constexpr int NBLK = NB * (NB + 1) / 2, NWV = kPotrfThreads / 64, PER = (NBLK + NWV - 1) / NWV;
-    const int wave = tid >> 6, lane = tid & 63;
     v4f64 accU[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) accU[u] = {0.0, 0.0, 0.0, 0.0};
@@ -180,15 +187,8 @@ __device__ __forceinline__ bool potrf_sweep(const double* __restrict__ A, double
         // the next source tile travels while this one is applied
         if (w + 1 < npre) { tile_load<TS>(Lt + (size_t)pre_tile[w + 1] * TS * TS, pre); if (tid < TS) ypre = y[pre_col[w + 1] * TS + tid]; }
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int bi = wave + NWV * u;
-            if (bi < NBLK) {
-                int a = 0;
-                while ((a + 1) * (a + 2) / 2 <= bi) ++a;
-                const int b = bi - a * (a + 1) / 2;
-                accU[u] = mfma_block_acc<TS, LD>(sL, 16 * a, sL, 16 * b, accU[u]);
-            }
-        }
+        for (int u = 0; u < PER; ++u)
+            if (own[u]) accU[u] = mfma_block_acc<TS, LD>(sL, 16 * ba[u], sL, 16 * bb[u], accU[u]);
         if (tid < TS) { // four partial sums: a single chain of TS dependent FP64 FMAs (36 cycles each) would cost 1.4 us
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll 6
@@ -202,46 +202,30 @@ __device__ __forceinline__ bool potrf_sweep(const double* __restrict__ A, double
         }
         __syncthreads();
     }
-    if (npre > 0) {
 #pragma unroll
-        for (int u = 0; u < PER; ++u) {
-            const int bi = wave + NWV * u;
-            if (bi < NBLK) {
-                int a = 0;
-                while ((a + 1) * (a + 2) / 2 <= bi) ++a;
-                const int b = bi - a * (a + 1) / 2;
+    for (int u = 0; u < PER; ++u)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) sX[(16 * a + (lane >> 4) + 4 * q) * LD + 16 * b + (lane & 15)] = accU[u][q];
-            }
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-#pragma unroll
-            for (int b = 0; b <= 2 * i + H; ++b) e[i][b] -= sX[(16 * (2 * i + H) + ty) * LD + 16 * b + tx];
-        __syncthreads();
-    }
-    if (stop_after == 5) { if (tid < TS) y[k * TS + tid] = e[0][0]; return true; }
+        for (int q = 0; q < 4; ++q) acc[u][q] -= accU[u][q];
+    if (stop_after == 5) { if (tid < TS) y[k * TS + tid] = acc[0][0]; return true; }
     long long t_clk0 = 0, t_rt0 = 0;
-    const int probe = (stop_after >= 6 && stop_after <= 9) ? stop_after : 0;
+    const bool probe = stop_after >= 6 && stop_after <= 9;
     if (probe) { t_clk0 = clock64(); t_rt0 = wall_clock64(); }
     bool fail = false;
-#pragma unroll
+    // (A look-ahead variant - next quad's block column updated and published first, the next pivot chain and the other
+    // blocks behind the same barrier, the two waves of a SIMD in opposite order - is correct but measured 33 us per
+    // tile instead of 25.6: the chain does not hide behind the other wave's work.)
     for (int jb = 0; jb < NB; ++jb) {
-        // first owned block row with a >= jb
-        const int i0 = (jb <= H) ? 0 : (jb - H + 1) / 2;
         for (int jq = 0; jq < 16 / KB; ++jq) {
             const int jx = KB * jq, j = 16 * jb + jx;
             double (*col)[TS] = s_col[jq & 1];
+            // the four columns of the quad, from the blocks of block column jb
 #pragma unroll
-            for (int m = 0; m < KB; ++m)
-                if (tx == jx + m) {
+            for (int u = 0; u < PER; ++u)
+                if (own[u] && bb[u] == jb && (ln >> 2) == jq) {
 #pragma unroll
-                    for (int i = 0; i < NI; ++i)
-                        if (i >= i0) col[m][16 * (2 * i + H) + ty] = e[i][jb];
+                    for (int q = 0; q < 4; ++q) col[ln & 3][16 * ba[u] + lk + 4 * q] = acc[u][q];
                 }
             __syncthreads();
-            if (probe == 9) continue;
             // KB x KB pivot block, LDL' in registers (every lane redundantly)
             double w[KB][KB], l[KB][KB], rinv[KB];
 #pragma unroll
@@ -260,47 +244,24 @@ __device__ __forceinline__ bool potrf_sweep(const double* __restrict__ A, double
                 if (tid == 0) s_rs[j + m] = dm;
             }
             if (fail) break;
-            if (probe == 8) { if (rinv[3] == 12345.0) e[0][0] += rinv[0]; continue; }
-            // eliminated panel entries of the owned rows (scaled by 1/d) and of the columns
-            double ur[KB][NI > 0 ? NI : 1], uc[KB][NB];
+            // eliminated panel entry of pivot lk at `row` (triangular solve against the pivot block), unscaled
+            auto panel = [&](int row) {
+                const double w0 = col[0][row];
+                const double w1 = fma(-w0, l[1][0], col[1][row]);
+                const double w2 = fma(-w1, l[2][1], fma(-w0, l[2][0], col[2][row]));
+                const double w3 = fma(-w2, l[3][2], fma(-w1, l[3][1], fma(-w0, l[3][0], col[3][row])));
+                return lk == 0 ? w0 : lk == 1 ? w1 : lk == 2 ? w2 : w3;
+            };
+            const double rk = lk == 0 ? rinv[0] : lk == 1 ? rinv[1] : lk == 2 ? rinv[2] : rinv[3];
 #pragma unroll
-            for (int i = 0; i < NI; ++i)
-                if (i >= i0) {
-                    double wr[KB];
-#pragma unroll
-                    for (int q = 0; q < KB; ++q) {
-                        double vr = col[q][16 * (2 * i + H) + ty];
-#pragma unroll
-                        for (int t = 0; t < q; ++t) vr = fma(-wr[t], l[q][t], vr);
-                        wr[q] = vr;
-                        ur[q][i] = vr * rinv[q];
-                    }
-                }
-#pragma unroll
-            for (int b = jb; b < NB; ++b) {
-                double wc[KB];
-#pragma unroll
-                for (int q = 0; q < KB; ++q) {
-                    double vc = col[q][16 * b + tx];
-#pragma unroll
-                    for (int t = 0; t < q; ++t) vc = fma(-wc[t], l[q][t], vc);
-                    wc[q] = vc;
-                    uc[q][b] = vc;
-                }
-            }
-            if (probe == 7) { if (ur[0][0] + uc[3][NB - 1] == 12345.0) e[0][0] += 1.0; continue; }
-#pragma unroll
-            for (int i = 0; i < NI; ++i)
-                if (i >= i0) {
-#pragma unroll
-                    for (int b = jb; b <= 2 * i + H; ++b) {
-                        // element (16a+ty, 16b+tx): pivot column j+q applies to columns c > j+q
-                        double v = e[i][b];
-#pragma unroll
-                        for (int q = 0; q < KB; ++q)
-                            if (b > jb || tx > jx + q) v = fma(-ur[q][i], uc[q][b], v);
-                        e[i][b] = v;
-                    }
+            for (int u = 0; u < PER; ++u)
+                if (own[u] && bb[u] >= jb) {
+                    const double wa = panel(16 * ba[u] + ln);
+                    const double wb = (ba[u] == bb[u]) ? wa : panel(16 * bb[u] + ln);
+                    // rows / columns up to the pivot stay as they are (in block row / column jb only)
+                    const double av = (ba[u] == jb && ln <= jx + lk) ? 0.0 : -wa * rk;
+                    const double bv = (bb[u] == jb && ln <= jx + lk) ? 0.0 : wb;
+                    acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[u], 0, 0, 0);
                 }
         }
         if (fail) break;
@@ -308,24 +269,25 @@ __device__ __forceinline__ bool potrf_sweep(const double* __restrict__ A, double
     __syncthreads();
     if (fail) return false;
     if (probe) { // shader cycles and 100 MHz ticks spent in the pivot sweep
-        if (tid == 0) { y[0] = (double)(clock64() - t_clk0); y[1] = (double)(wall_clock64() - t_rt0); y[2] = e[0][0]; }
+        if (tid == 0) { y[0] = (double)(clock64() - t_clk0); y[1] = (double)(wall_clock64() - t_rt0); y[2] = acc[0][0]; }
         return true;
     }
-    if (stop_after == 1) { if (tid < TS) y[k * TS + tid] = e[0][0]; return true; }
+    if (stop_after == 1) { if (tid < TS) y[k * TS + tid] = acc[0][0]; return true; }
     if (tid < TS) s_rs[tid] = fast_rsqrt(s_rs[tid]);
+    for (int i = tid; i < TS * LD; i += kPotrfThreads) { sL[i] = 0.0; sX[i] = 0.0; }
     __syncthreads();
-    // L[r][c] = A[r][c] / sqrt(d_c) -> LDS image (zero upper triangle), zeroed X, global L tile
+    // L[r][c] = A[r][c] / sqrt(d_c) -> LDS image (zero upper triangle), then the global L tile from the image
 #pragma unroll
-    for (int i = 0; i < NI; ++i)
+    for (int u = 0; u < PER; ++u)
+        if (own[u]) {
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int r = 16 * (2 * i + H) + ty, c = 16 * b + tx;
-            double v = 0.0;
-            if (b <= 2 * i + H && c <= r) v = e[i][b <= 2 * i + H ? b : 0] * s_rs[c];
-            sL[r * LD + c] = v;
-            sX[r * LD + c] = 0.0;
-            Lg[r * TS + c] = v;
+            for (int q = 0; q < 4; ++q) {
+                const int r = 16 * ba[u] + lk + 4 * q, c = 16 * bb[u] + ln;
+                if (c <= r) sL[r * LD + c] = acc[u][q] * s_rs[c];
+            }
         }
+    __syncthreads();
+    for (int i = tid; i < TS * TS; i += kPotrfThreads) Lg[i] = sL[(i / TS) * LD + (i % TS)];
     return true;
 }
 
@@ -380,10 +342,7 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
     const double* A = S + (size_t)tile_id * TS * TS;
     double* Lg = Lt + (size_t)tile_id * TS * TS;
     if (tid < TS) s_g[tid] = g[k * TS + tid];
-    const int half = __builtin_amdgcn_readfirstlane(tid >> 8); // wave-uniform
-    bool ok;
-    if (half == 0) ok = potrf_sweep<TS, 0>(A, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y, Lt, sa.pre_tile + pre0, sa.pre_col + pre0, npre, s_g);
-    else           ok = potrf_sweep<TS, 1>(A, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y, Lt, sa.pre_tile + pre0, sa.pre_col + pre0, npre, s_g);
+    const bool ok = potrf_sweep_mfma<TS>(A, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y, Lt, sa.pre_tile + pre0, sa.pre_col + pre0, npre, s_g);
     if (!ok) { if (tid == 0) *status = k + 1; return; }
     if (stop_after == 5 || (stop_after >= 6 && stop_after <= 9) || stop_after == 1) return;
     __syncthreads();
