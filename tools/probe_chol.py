@@ -9,7 +9,7 @@ for tile in (48,96):
         rc=lib.svi_debug_chol_probe(0,tile,300,stop,C.cast(C.byref(ms), C.POINTER(C.c_double)))
         out.append("%d:%.2fus"%(stop,ms.value*1e3))
     print(tile, " ".join(out))
-    for mode,name in ((6,"full sweep"),(7,"no update"),(8,"publish+barrier+pivot chain"),(9,"publish+barrier only")):
+    for mode,name in ((6,"full sweep"),):
         arr=(C.c_double*2)()
         lib.svi_debug_chol_probe(0,tile,50,mode,arr)
         cyc,ticks=arr[0],arr[1]
