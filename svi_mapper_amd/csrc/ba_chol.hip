@@ -295,6 +295,7 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
 struct StepArgs {
     int n_chain;                 // workgroups 0..n_chain-1 factorise one column each, the rest run grouped updates
     const int* chain_col;        // [n_chain] tile columns of this level
+    const int4* chain_desc;      // [n_chain] pairs of int4: {column, diagonal tile, first pre, #pre}, {first sub-diagonal tile, #, 0, 0}
     const int* diag_tile;        // [NT]
     const int* pre_ptr;          // [NT+1]
     const int* pre_tile;
@@ -336,9 +337,8 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
     const int tid = threadIdx.x;
     if (*status != 0) return;
     if ((int)blockIdx.x >= sa.n_chain) { gemm_target_block<TS>(S, Lt, sa, (int)blockIdx.x - sa.n_chain, g, y, sm); return; }
-    const int k = sa.chain_col[blockIdx.x];
-    const int tile_id = sa.diag_tile[k];
-    const int pre0 = sa.pre_ptr[k], npre = sa.pre_ptr[k + 1] - pre0;
+    const int4 ds = sa.chain_desc[2 * blockIdx.x];
+    const int k = ds.x, tile_id = ds.y, pre0 = ds.z, npre = ds.w;
     const double* A = S + (size_t)tile_id * TS * TS;
     double* Lg = Lt + (size_t)tile_id * TS * TS;
     if (tid < TS) s_g[tid] = g[k * TS + tid];
@@ -544,7 +544,7 @@ __device__ void gemm_target_block(double* __restrict__ S, const double* __restri
 // ---------------------------------------------------------------------------------------------
 template <int TS>
 __global__ __launch_bounds__(kPotrfThreads) void k_back_solve(const double* __restrict__ Lt, const double* __restrict__ Linv, double* x, CholPlan p,
-                                                              const int* __restrict__ cols, const int* status)
+                                                              const int4* __restrict__ desc, const int* status)
 {
     constexpr int NW = kPotrfThreads / 64;
     __shared__ double s_part[NW][TS];
@@ -552,8 +552,8 @@ __global__ __launch_bounds__(kPotrfThreads) void k_back_solve(const double* __re
     __shared__ double s_acc[TS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int failed = *status; // tested once the first loads are on their way
-    const int k = cols[blockIdx.x];
-    const int q0 = p.col_ptr[k], nq = p.col_ptr[k + 1] - q0;
+    const int4 d0 = desc[2 * blockIdx.x], d1 = desc[2 * blockIdx.x + 1];
+    const int k = d0.x, q0 = d1.x, nq = d1.y;
     const int c0 = lane < TS ? lane : TS - 1, c1 = lane + 64 < TS ? lane + 64 : TS - 1;
     // this wave's rows of Linv_kk for step (2): they depend on nothing, so they travel while step (1) runs
     constexpr int RW = (TS + NW - 1) / NW;
@@ -647,7 +647,7 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
     for (int st = 0; st < p.n_steps; ++st) {
         const int c0 = p.h_step_ptr[st], nc = p.h_step_ptr[st + 1] - c0;
         const int t0 = p.h_tgt_ptr[st], ntg = p.h_tgt_ptr[st + 1] - t0;
-        sa.n_chain = nc; sa.chain_col = p.step_col + c0;
+        sa.n_chain = nc; sa.chain_col = p.step_col + c0; sa.chain_desc = reinterpret_cast<const int4*>(p.step_desc) + 2 * c0;
         sa.tgt_tile = p.tgt_tile + t0; sa.tgt_row = p.tgt_row + t0; sa.tgt_pair_ptr = p.tgt_pair_ptr + t0;
         hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(nc + ntg * Q * Q), dim3(kPotrfThreads), lds_p, s, S, Lt, Linv, g, x, n, lambda, status, 0, sa);
         const int i0 = p.h_trsm_ptr[st], ni = p.h_trsm_ptr[st + 1] - i0;
@@ -655,7 +655,7 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
     }
     for (int st = p.n_steps - 1; st >= 0; --st) {
         const int c0 = p.h_step_ptr[st], nc = p.h_step_ptr[st + 1] - c0;
-        hipLaunchKernelGGL(k_back_solve<TS>, dim3(nc), dim3(kPotrfThreads), 0, s, Lt, Linv, x, p, p.step_col + c0, status);
+        hipLaunchKernelGGL(k_back_solve<TS>, dim3(nc), dim3(kPotrfThreads), 0, s, Lt, Linv, x, p, reinterpret_cast<const int4*>(p.step_desc) + 2 * c0, status);
     }
     return 0;
 }
@@ -671,16 +671,16 @@ static int potrf_probe(int reps, int stop_after, double* ms_out)
     const size_t lds_p = sizeof(double) * 2 * (size_t)TS * LD;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv<TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p) != hipSuccess) return 1;
     double *S = nullptr, *L = nullptr, *X = nullptr, *g = nullptr, *y = nullptr;
-    int *st = nullptr, *tab = nullptr; // tab: chain_col[0] = 0, diag_tile[0] = 0, pre_ptr = {0, 0}
+    int *st = nullptr, *tab = nullptr; // tab: an all-zero column record (column 0, tile 0, nothing pending)
     std::vector<double> h((size_t)TS * TS);
     for (int r = 0; r < TS; ++r)
         for (int c = 0; c < TS; ++c) h[(size_t)r * TS + c] = (r == c ? TS + 1.0 : 0.0) + 1.0 / (1.0 + r + c);
     if (hipMalloc(&S, sizeof(double) * TS * TS) != hipSuccess) return 1;
     (void)hipMalloc(&L, sizeof(double) * TS * TS); (void)hipMalloc(&X, sizeof(double) * TS * TS);
     (void)hipMalloc(&g, sizeof(double) * TS); (void)hipMalloc(&y, sizeof(double) * TS); (void)hipMalloc(&st, sizeof(int));
-    (void)hipMalloc(&tab, 4 * sizeof(int)); (void)hipMemset(tab, 0, 4 * sizeof(int));
+    (void)hipMalloc(&tab, 8 * sizeof(int)); (void)hipMemset(tab, 0, 8 * sizeof(int));
     StepArgs sa{};
-    sa.n_chain = 1; sa.chain_col = tab; sa.diag_tile = tab; sa.pre_ptr = tab;
+    sa.n_chain = 1; sa.chain_col = tab; sa.diag_tile = tab; sa.pre_ptr = tab; sa.chain_desc = reinterpret_cast<const int4*>(tab);
     (void)hipMemcpy(S, h.data(), sizeof(double) * TS * TS, hipMemcpyHostToDevice);
     (void)hipMemset(g, 0, sizeof(double) * TS); (void)hipMemset(st, 0, sizeof(int));
     hipEvent_t a, b;

@@ -143,6 +143,7 @@ struct CholPlan {
     const int* h_trsm_ptr = nullptr;  // [n_steps+1] into st_tile / st_col
     // device
     const int* step_col = nullptr;    // tile columns of each level, ascending
+    const int* step_desc = nullptr;   // [len(step_col)][8]: column, its diagonal tile, pre_ptr, #pre, col_ptr, #sub-diagonal tiles, 0, 0
     const int* diag_tile = nullptr;   // [NT] tile id of (k,k)
     const int* pre_ptr = nullptr;     // [NT+1]: updates of (k,k) applied by the workgroup that factorises it
     const int* pre_tile = nullptr;    //   tile (k,q)

@@ -841,6 +841,18 @@ int build_structure(svi_ba* ba)
     SVI_TRY(dev_upload(ba, trsm_tile, &p.trsm_tile));
     SVI_TRY(dev_upload(ba, trsm_row, &p.trsm_row));
     SVI_TRY(dev_upload(ba, step_col, &p.step_col));
+    {
+        // everything a chain / back-substitution workgroup needs to know about its column in ONE record (two 16-byte
+        // loads side by side instead of a chain of three dependent index loads at the start of every launch)
+        std::vector<int> step_desc((size_t)8 * std::max<size_t>(step_col.size(), 1), 0);
+        for (size_t q = 0; q < step_col.size(); ++q) {
+            const int c = step_col[q];
+            int* r = &step_desc[8 * q];
+            r[0] = c; r[1] = diag_tile[c]; r[2] = pre_ptr[c]; r[3] = pre_ptr[c + 1] - pre_ptr[c];
+            r[4] = h_col_ptr[c]; r[5] = h_col_ptr[c + 1] - h_col_ptr[c];
+        }
+        SVI_TRY(dev_upload(ba, step_desc, &p.step_desc));
+    }
     SVI_TRY(dev_upload(ba, diag_tile, &p.diag_tile));
     SVI_TRY(dev_upload(ba, pre_ptr, &p.pre_ptr));
     SVI_TRY(dev_upload(ba, pre_tile, &p.pre_tile));
