@@ -241,7 +241,12 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
                 const double dm = w[m][m];
                 if (!(dm > 0.0)) fail = true; // uniform: every lane sees the same pivot block
                 rinv[m] = fast_rcp(dm);
-                if (tid == 0) s_rs[j + m] = dm;
+            }
+            // (the pivots go out AFTER the chain: a store inside it would put its LDS round trip, through the wait
+            // for the next column's reads, on the dependent path of every column)
+            if (tid == 0) {
+#pragma unroll
+                for (int m = 0; m < KB; ++m) s_rs[j + m] = w[m][m];
             }
             if (fail) break;
             // eliminated panel entry of pivot lk at `row` (triangular solve against the pivot block), unscaled
