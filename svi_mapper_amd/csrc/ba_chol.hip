@@ -242,12 +242,6 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
                 if (!(dm > 0.0)) fail = true; // uniform: every lane sees the same pivot block
                 rinv[m] = fast_rcp(dm);
             }
-            // (the pivots go out AFTER the chain: a store inside it would put its LDS round trip, through the wait
-            // for the next column's reads, on the dependent path of every column)
-            if (tid == 0) {
-#pragma unroll
-                for (int m = 0; m < KB; ++m) s_rs[j + m] = w[m][m];
-            }
             if (fail) break;
             // eliminated panel entry of pivot lk at `row` (triangular solve against the pivot block), unscaled
             auto panel = [&](int row) {
@@ -268,6 +262,12 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
                     const double bv = (bb[u] == jb && ln <= jx + lk) ? 0.0 : wb;
                     acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[u], 0, 0, 0);
                 }
+            // the pivots go out LAST: a store inside the chain (or in front of the panel reads) would put its LDS round
+            // trip, through the in-order wait for the next reads, on the dependent path
+            if (tid == 0) {
+#pragma unroll
+                for (int m = 0; m < KB; ++m) s_rs[j + m] = w[m][m];
+            }
         }
         if (fail) break;
     }
@@ -330,15 +330,13 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
     extern __shared__ __align__(16) double sm[];
     double* sL = sm;            // [TS][LD]
     double* sX = sm + TS * LD;  // [TS][LD]
-    // one scratch block serves the pivot sweep (published columns, [parity][column of the quad][row])
-    // and later the inverse (per-wave 16x16 staging): the two never overlap in time
-    constexpr int kScratch = (2 * 4 * TS > (NB - 1) * 256) ? 2 * 4 * TS : (NB - 1) * 256;
+    // scratch of the pivot sweep: the published columns, [parity][column of the quad][row]
+    constexpr int kScratch = 2 * 4 * TS;
     __shared__ double s_buf[kScratch];
     __shared__ double s_rs[TS];        // 1/sqrt(d_j) = 1/L_jj
     __shared__ double s_g[TS];
     static_assert(sizeof(double) * (2 * TS * LD + kScratch + 2 * TS) <= 160 * 1024, "potrf LDS budget (160 KiB per workgroup)");
     double (*s_col)[4][TS] = reinterpret_cast<double (*)[4][TS]>(s_buf);
-    double (*s_T)[16 * 16] = reinterpret_cast<double (*)[16 * 16]>(s_buf);
     const int tid = threadIdx.x;
     if (*status != 0) return;
     if ((int)blockIdx.x >= sa.n_chain) { gemm_target_block<TS>(S, Lt, sa, (int)blockIdx.x - sa.n_chain, g, y, sm); return; }
@@ -373,9 +371,13 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
     // (2) off-diagonal blocks, one block column per wave: X_ij = -X_ii * sum_{m=j}^{i-1} L_im X_mj
     {
         const int wave = tid >> 6, lane = tid & 63;
-        double* sT = s_T[wave];
         for (int j = wave; j < NB - 1; j += kPotrfThreads / 64) {
             for (int i = j + 1; i < NB; ++i) {
+                // X_ii operand first: it depends on nothing of this step
+                const double* pd = sX + (16 * i + (lane & 15)) * LD + 16 * i + (lane >> 4);
+                double dv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) dv[q] = pd[4 * q];
                 v4f64 acc = {0.0, 0.0, 0.0, 0.0};
                 for (int m = j; m < i; ++m) {
                     const double* pa = sL + (16 * i + (lane & 15)) * LD + 16 * m + (lane >> 4);
@@ -386,18 +388,11 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
                 }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) sT[((lane >> 4) + 4 * q) * 16 + (lane & 15)] = acc[q];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
+                // the accumulator layout (row (lane>>4) + 4q, column lane&15) IS the B-operand layout of the next product
+                // (k = (lane>>4) + 4q, n = lane&15): no trip through LDS
                 v4f64 r = {0.0, 0.0, 0.0, 0.0};
-                const double* pd = sX + (16 * i + (lane & 15)) * LD + 16 * i + (lane >> 4);
-                const double* pt = sT + (lane >> 4) * 16 + (lane & 15);
-                double dv[4], tv[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) { dv[q] = pd[4 * q]; tv[q] = pt[4 * q * 16]; }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) r = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[q], tv[q], r, 0, 0, 0);
+                for (int q = 0; q < 4; ++q) r = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[q], acc[q], r, 0, 0, 0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q) sX[(16 * i + (lane >> 4) + 4 * q) * LD + 16 * j + (lane & 15)] = -r[q];
                 __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
