@@ -279,9 +279,11 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
     }
     if (stop_after == 1) { if (tid < TS) y[k * TS + tid] = acc[0][0]; return true; }
     if (tid < TS) s_rs[tid] = fast_rsqrt(s_rs[tid]);
-    for (int i = tid; i < TS * LD; i += kPotrfThreads) { sL[i] = 0.0; sX[i] = 0.0; }
+    for (int i = tid; i < TS * LD; i += kPotrfThreads) sX[i] = 0.0; // X is read whole (y_k, the store): zero above the diagonal
     __syncthreads();
-    // L[r][c] = A[r][c] / sqrt(d_c) -> LDS image (zero upper triangle), then the global L tile from the image
+    // L[r][c] = A[r][c] / sqrt(d_c) -> LDS image.  Only its lower triangle is ever read (by the inverse below), and the
+    // diagonal factor itself is needed nowhere else - trsm, the updates and the substitutions work with L_kk^-1 - so
+    // neither the upper triangle of the image nor a copy in global memory is written.
 #pragma unroll
     for (int u = 0; u < PER; ++u)
         if (own[u]) {
@@ -291,8 +293,6 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
                 if (c <= r) sL[r * LD + c] = acc[u][q] * s_rs[c];
             }
         }
-    __syncthreads();
-    for (int i = tid; i < TS * TS; i += kPotrfThreads) Lg[i] = sL[(i / TS) * LD + (i % TS)];
     return true;
 }
 
