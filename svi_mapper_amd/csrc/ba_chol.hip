@@ -338,9 +338,10 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
     static_assert(sizeof(double) * (2 * TS * LD + kScratch + 2 * TS) <= 160 * 1024, "potrf LDS budget (160 KiB per workgroup)");
     double (*s_col)[4][TS] = reinterpret_cast<double (*)[4][TS]>(s_buf);
     const int tid = threadIdx.x;
-    if (*status != 0) return;
+    const int failed = *status; // tested together with the column record: one round trip, not two
+    const int4 ds = sa.chain_desc[2 * ((int)blockIdx.x < sa.n_chain ? (int)blockIdx.x : 0)];
+    if (failed != 0) return;
     if ((int)blockIdx.x >= sa.n_chain) { gemm_target_block<TS>(S, Lt, sa, (int)blockIdx.x - sa.n_chain, g, y, sm); return; }
-    const int4 ds = sa.chain_desc[2 * blockIdx.x];
     const int k = ds.x, tile_id = ds.y, pre0 = ds.z, npre = ds.w;
     const double* A = S + (size_t)tile_id * TS * TS;
     double* Lg = Lt + (size_t)tile_id * TS * TS;
