@@ -243,22 +243,28 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
                 rinv[m] = fast_rcp(dm);
             }
             if (fail) break;
-            // eliminated panel entry of pivot lk at `row` (triangular solve against the pivot block), unscaled
-            auto panel = [&](int row) {
-                const double w0 = col[0][row];
-                const double w1 = fma(-w0, l[1][0], col[1][row]);
-                const double w2 = fma(-w1, l[2][1], fma(-w0, l[2][0], col[2][row]));
-                const double w3 = fma(-w2, l[3][2], fma(-w1, l[3][1], fma(-w0, l[3][0], col[3][row])));
-                return lk == 0 ? w0 : lk == 1 ? w1 : lk == 2 ? w2 : w3;
-            };
-            const double rk = lk == 0 ? rinv[0] : lk == 1 ? rinv[1] : lk == 2 ? rinv[2] : rinv[3];
+            // Panel entries by the INVERSE of the unit-triangular pivot factor: the eliminated entry of pivot lk at a row
+            // is then one short dot product of the four published values with this lane's coefficient row (no chain of
+            // dependent FP64 operations and no per-solve selects), the 1/d scaling of the row operand folded in.
+            const double c10 = -l[1][0], c21 = -l[2][1], c32 = -l[3][2];
+            const double c20 = fma(-l[2][1], c10, -l[2][0]), c31 = fma(-l[3][2], c21, -l[3][1]);
+            const double c30 = fma(-l[3][2], c20, fma(-l[3][1], c10, -l[3][0]));
+            const double cl0 = lk == 0 ? 1.0 : lk == 1 ? c10 : lk == 2 ? c20 : c30;
+            const double cl1 = lk == 0 ? 0.0 : lk == 1 ? 1.0 : lk == 2 ? c21 : c31;
+            const double cl2 = lk < 2 ? 0.0 : lk == 2 ? 1.0 : c32;
+            const double cl3 = lk == 3 ? 1.0 : 0.0;
+            const double rk = -(lk == 0 ? rinv[0] : lk == 1 ? rinv[1] : lk == 2 ? rinv[2] : rinv[3]);
+            const double ca0 = cl0 * rk, ca1 = cl1 * rk, ca2 = cl2 * rk, ca3 = cl3 * rk;
 #pragma unroll
             for (int u = 0; u < PER; ++u)
                 if (own[u] && bb[u] >= jb) {
-                    const double wa = panel(16 * ba[u] + ln);
-                    const double wb = (ba[u] == bb[u]) ? wa : panel(16 * bb[u] + ln);
+                    const int ra = 16 * ba[u] + ln, rb = 16 * bb[u] + ln;
+                    const double a0 = col[0][ra], a1 = col[1][ra], a2 = col[2][ra], a3 = col[3][ra];
+                    const double b0 = col[0][rb], b1 = col[1][rb], b2 = col[2][rb], b3 = col[3][rb];
+                    const double wa = fma(ca1, a1, ca0 * a0) + fma(ca3, a3, ca2 * a2); // = -w[lk] / d[lk] at row ra
+                    const double wb = fma(cl1, b1, cl0 * b0) + fma(cl3, b3, cl2 * b2); // =  w[lk]         at row rb
                     // rows / columns up to the pivot stay as they are (in block row / column jb only)
-                    const double av = (ba[u] == jb && ln <= jx + lk) ? 0.0 : -wa * rk;
+                    const double av = (ba[u] == jb && ln <= jx + lk) ? 0.0 : wa;
                     const double bv = (bb[u] == jb && ln <= jx + lk) ? 0.0 : wb;
                     acc[u] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[u], 0, 0, 0);
                 }

@@ -1545,11 +1545,12 @@ int svi_debug_chol_probe(int device, int tile, int reps, int stop_after, double*
 {
     if (!ms || reps < 1 || (tile != 48 && tile != 96)) return fail(SVI_ERR_INVALID, "bad probe argument");
     if (int rc = use_device(device)) return rc;
-    double out[2] = {0, 0};
+    double out[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     if (chol_potrf_probe(tile, reps, stop_after, out)) return fail(SVI_ERR_HIP, "probe failed");
-    // stop_after == 6: shader cycles of the pivot sweep in ms[0] and 100 MHz ticks in ms[1] (caller passes room for 2)
+    // stop_after 6..9: shader cycles of the pivot sweep in ms[0], 100 MHz ticks in ms[1], per-section cycle sums in
+    // ms[3..5] (the caller passes room for 8 doubles); otherwise the mean kernel time in ms[0]
     ms[0] = out[0];
-    if (stop_after >= 6 && stop_after <= 9) ms[1] = out[1];
+    if (stop_after >= 6 && stop_after <= 9) for (int q = 1; q < 6; ++q) ms[q] = out[q];
     return SVI_OK;
 }
 

@@ -10,7 +10,7 @@ for tile in (48,96):
         out.append("%d:%.2fus"%(stop,ms.value*1e3))
     print(tile, " ".join(out))
     for mode,name in ((6,"full sweep"),):
-        arr=(C.c_double*2)()
+        arr=(C.c_double*8)()
         lib.svi_debug_chol_probe(0,tile,50,mode,arr)
         cyc,ticks=arr[0],arr[1]
         print("   %-30s %.0f shader cycles, %.2f us, clock %.2f GHz" % (name, cyc, ticks*0.01, cyc/(ticks*10.0) if ticks else 0))
