@@ -432,6 +432,27 @@ def test_g2o_round_trip(svi, small, tmp_path):
     assert _rel(Ta, Tb) < 1e-9  # quaternion text round trip of the initial rotations
 
 
+def test_c4_first_iterations_parity(svi, oracle):
+    """BASELINE config 4 at FULL size against the oracle: optimize(1) + optimize(2) (the oracle's full-system sparse
+    factorisation takes about half a second per iteration, so three iterations is what fits a test) - the nine-level
+    tile Cholesky, the cell-based Schur reduction and the sharded work lists at the size the benchmark is quoted on."""
+    prob = synth.make_c4()
+    g, sg = _make(svi.BundleAdjuster, prob)
+    o, so = _make(oracle.OracleBA, prob)
+    np.testing.assert_array_equal(sg, so)
+    g.initialize()
+    o.initialize()
+    for n in (1, 2):
+        assert g.optimize(n) == o.optimize(n)
+    _, Tg = g.get_poses()
+    _, To = o.get_poses()
+    _, pg = g.get_landmarks()
+    _, po = o.get_landmarks()
+    assert _rel(Tg[:, 9:], To[:, 9:]) < REL and np.abs(Tg[:, :9] - To[:, :9]).max() < REL and _rel(pg, po) < REL
+    assert abs(g.last_plain_chi2 - o.last_plain_chi2) <= 1e-6 * o.last_plain_chi2
+    assert g.stats().chol_steps >= 5  # the level-scheduled path, not a single chain
+
+
 def test_c4_properties(svi):
     """BASELINE config 4 (500 KF / 100 k landmarks / 800 k edges), size-independent properties:
     accepted LM steps never increase the robust chi2, the result is reproducible run to run, and a
