@@ -155,14 +155,22 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
     int ba[PER], bb[PER];
     bool own[PER];
     v4f64 acc[PER];
+    // Which blocks a wave owns.  The pivot chain runs redundantly on all eight waves, but the four that share a SIMD
+    // with an older wave issue behind it (measured: 480 vs 795 cycles per quad), and a block is live only while its
+    // block column has not been passed: the tables give the long-lived blocks to the fast waves and the slow waves
+    // one block less, from a greedy search over per-quad cost = chain(wave) + 250 x live blocks (tools note in DESIGN).
+    static constexpr signed char kOwn6[8][3][2] = {{{5, 5}, {4, 3}, {3, 1}}, {{5, 4}, {3, 3}, {2, 1}}, {{4, 4}, {5, 2}, {1, 1}},
+                                                   {{5, 3}, {4, 2}, {5, 0}}, {{3, 2}, {4, 0}, {0, 0}}, {{2, 2}, {3, 0}, {-1, -1}},
+                                                   {{5, 1}, {2, 0}, {-1, -1}}, {{4, 1}, {1, 0}, {-1, -1}}};
+    static constexpr signed char kOwn3[8][1][2] = {{{2, 2}}, {{2, 1}}, {{1, 1}}, {{2, 0}}, {{1, 0}}, {{0, 0}}, {{-1, -1}}, {{-1, -1}}};
+    static_assert((NB == 6 && PER == 3) || (NB == 3 && PER == 1), "block ownership tables exist for 96 and 48 wide tiles");
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-        const int bi = wave + NWV * u;
-        own[u] = bi < NBLK;
-        int a = 0;
-        while ((a + 1) * (a + 2) / 2 <= bi) ++a;
-        ba[u] = own[u] ? a : 0;
-        bb[u] = own[u] ? bi - a * (a + 1) / 2 : 0;
+        const int ta = NB == 6 ? kOwn6[wave][u < 3 ? u : 0][0] : kOwn3[wave][0][0];
+        const int tb = NB == 6 ? kOwn6[wave][u < 3 ? u : 0][1] : kOwn3[wave][0][1];
+        own[u] = ta >= 0;
+        ba[u] = own[u] ? ta : 0;
+        bb[u] = own[u] ? tb : 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = 16 * ba[u] + lk + 4 * q, c = 16 * bb[u] + ln;
