@@ -252,7 +252,7 @@ __global__ __launch_bounds__(kBlock) void k_linearize_lm(BaDev d, int cur)
 #pragma unroll
             for (int k = 0; k < 9; ++k) stp(d.NZ + (size_t)k * E, (unsigned)e * 8u, lfix ? 0.0 : N[k]);
 #pragma unroll
-            for (int k = 0; k < 3; ++k) stp(d.NZ + (size_t)(9 + k) * E, (unsigned)e * 8u, Z[k]);
+            for (int k = 0; k < 3; ++k) stp(d.NZ + (size_t)(9 + k) * E, (unsigned)e * 8u, 2.0 * Z[k]); // stored doubled: every consumer needs K = 2[Z]x
             // H_ll contribution R N (symmetric, upper 00 01 02 11 12 22) and b_l = -R u
             int k = 0;
 #pragma unroll
@@ -832,8 +832,8 @@ __global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
 #pragma unroll
                 for (int r = 0; r < 3; ++r) M[3 * r + c] = T[3 * r] * w0 + T[3 * r + 1] * w1 + T[3 * r + 2] * w2;
             }
-            const double a0 = 2.0 * na[9], a1 = 2.0 * na[10], a2 = 2.0 * na[11];
-            const double b0 = 2.0 * nbp[9], b1 = 2.0 * nbp[10], b2 = 2.0 * nbp[11];
+            const double a0 = na[9], a1 = na[10], a2 = na[11];   // 2 Z_a (stored doubled by the sweep)
+            const double b0 = nbp[9], b1 = nbp[10], b2 = nbp[11]; // 2 Z_b
             // KM = Ka M
             double KM[9];
 #pragma unroll
@@ -1014,7 +1014,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub_chi2(BaDev d, int cur, doubl
             double v[3] = {0.0, 0.0, 0.0};
             if (r >= 0) { // H_pl' dx = N' ( -dt + 2 Z x dq )
                 const unsigned eo = (unsigned)e * 8u;
-                const double z0 = 2.0 * ldp(d.NZ + 9 * E, eo), z1 = 2.0 * ldp(d.NZ + 10 * E, eo), z2 = 2.0 * ldp(d.NZ + 11 * E, eo);
+                const double z0 = ldp(d.NZ + 9 * E, eo), z1 = ldp(d.NZ + 10 * E, eo), z2 = ldp(d.NZ + 11 * E, eo); // 2 Z (stored doubled)
                 const double* dxp = d.dx + 6 * r;
                 const double u0 = -dxp[0] + (z1 * dxp[5] - z2 * dxp[4]);
                 const double u1 = -dxp[1] + (z2 * dxp[3] - z0 * dxp[5]);
