@@ -79,7 +79,7 @@ struct BaDev {
     const int*    pose_aux_ref; // se3 edge k as (k<<2)|0 (role i) or |1 (role j); accel edge k as (k<<2)|2
 
     // linearisation outputs
-    double* NZ;       // [12][E]  per edge: N = A'(rho1 Omega)A R' (3x3 row-major, planes 0-8) and Z = R'(p-t) (planes 9-11);
+    double* NZ;       // [6][E] double2: per edge N = A'(rho1 Omega)A R' (3x3 row-major, values 0-8) and 2Z, Z = R'(p-t) (values 9-11);
                       //          H_pl = [ -N ; -2[Z]x N ] is never materialised
     double* Hll;      // [6][Ll]  upper triangle of H_ll
     double* bl;       // [3][Ll]

@@ -144,6 +144,17 @@ __device__ __forceinline__ void stp(double* __restrict__ base, unsigned byte_off
 {
     *reinterpret_cast<double*>(reinterpret_cast<char*>(base) + (size_t)byte_off) = v;
 }
+// The per-edge operands N (9) and 2Z (3) live in SIX planes of double2: plane p holds values 2p, 2p+1 of edge e at
+// NZ2[p E + e].  Writers and readers stay fully coalesced (16 B per lane) and need half the memory instructions of
+// twelve 8-byte planes.
+__device__ __forceinline__ double2 ldp2(const double* __restrict__ nz, size_t E, int p, unsigned e)
+{
+    return *reinterpret_cast<const double2*>(reinterpret_cast<const char*>(nz + 2 * (size_t)p * E) + (size_t)(e * 16u));
+}
+__device__ __forceinline__ void stp2(double* __restrict__ nz, size_t E, int p, unsigned e, double a, double b)
+{
+    *reinterpret_cast<double2*>(reinterpret_cast<char*>(nz + 2 * (size_t)p * E) + (size_t)(e * 16u)) = make_double2(a, b);
+}
 
 template <bool DIAG>
 __device__ __forceinline__ void load_edge(const double* __restrict__ zp, const double* __restrict__ ip,
@@ -249,10 +260,13 @@ __global__ __launch_bounds__(kBlock) void k_linearize_lm(BaDev d, int cur)
             for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) N[3 * r + c] = Cf[3 * r] * R[3 * c] + Cf[3 * r + 1] * R[3 * c + 1] + Cf[3 * r + 2] * R[3 * c + 2];
+            double nz[12]; // N (zero for a fixed landmark), then 2Z: every consumer needs K = 2[Z]x
 #pragma unroll
-            for (int k = 0; k < 9; ++k) stp(d.NZ + (size_t)k * E, (unsigned)e * 8u, lfix ? 0.0 : N[k]);
+            for (int k = 0; k < 9; ++k) nz[k] = lfix ? 0.0 : N[k];
 #pragma unroll
-            for (int k = 0; k < 3; ++k) stp(d.NZ + (size_t)(9 + k) * E, (unsigned)e * 8u, 2.0 * Z[k]); // stored doubled: every consumer needs K = 2[Z]x
+            for (int k = 0; k < 3; ++k) nz[9 + k] = 2.0 * Z[k];
+#pragma unroll
+            for (int pp = 0; pp < 6; ++pp) stp2(d.NZ, (size_t)E, pp, (unsigned)e, nz[2 * pp], nz[2 * pp + 1]);
             // H_ll contribution R N (symmetric, upper 00 01 02 11 12 22) and b_l = -R u
             int k = 0;
 #pragma unroll
@@ -735,7 +749,7 @@ __device__ __forceinline__ void schur_fetch(const BaDev& d, const int4 (&pk)[kSc
 {
     const int es = lane & 7, pg = (lane >> 3) & 1, l16 = lane & 15;
     const size_t E = d.E;
-    const double* __restrict__ plane0 = d.NZ + (size_t)(6 * pg) * E; // this lane's first plane
+    const double* __restrict__ nzp = d.NZ;
 #pragma unroll
     for (int t = 0; t < kSchurBatch; ++t) {
         st.m[t] = pk[t].w;
@@ -746,9 +760,11 @@ __device__ __forceinline__ void schur_fetch(const BaDev& d, const int4 (&pk)[kSc
         const bool row = es < 4;
         const bool on = row ? (es < nI) : (es - 4 < nJ);
         const unsigned e = on ? (unsigned)((row ? pk[t].y : pk[t].z - 4) + es) : 0u;
-        const double* __restrict__ src = plane0 + e;
 #pragma unroll
-        for (int q = 0; q < 6; ++q) st.v[t][q] = src[(size_t)q * E];
+        for (int q = 0; q < 3; ++q) { // the lane's six values are three double2 planes
+            const double2 x = ldp2(nzp, E, 3 * pg + q, e);
+            st.v[t][2 * q] = x.x; st.v[t][2 * q + 1] = x.y;
+        }
         st.hv[t] = d.HinvB[(size_t)12 * (unsigned)pk[t].x + (l16 < 9 ? l16 : 0)];
     }
 }
@@ -1013,15 +1029,16 @@ __global__ __launch_bounds__(kBlock) void k_backsub_chi2(BaDev d, int cur, doubl
             const int r = d.pose_red[s];
             double v[3] = {0.0, 0.0, 0.0};
             if (r >= 0) { // H_pl' dx = N' ( -dt + 2 Z x dq )
-                const unsigned eo = (unsigned)e * 8u;
-                const double z0 = ldp(d.NZ + 9 * E, eo), z1 = ldp(d.NZ + 10 * E, eo), z2 = ldp(d.NZ + 11 * E, eo); // 2 Z (stored doubled)
+                double nz[12]; // N (9), 2Z (3): six double2 planes
+#pragma unroll
+                for (int pp = 0; pp < 6; ++pp) { const double2 x = ldp2(d.NZ, E, pp, (unsigned)e); nz[2 * pp] = x.x; nz[2 * pp + 1] = x.y; }
+                const double z0 = nz[9], z1 = nz[10], z2 = nz[11];
                 const double* dxp = d.dx + 6 * r;
                 const double u0 = -dxp[0] + (z1 * dxp[5] - z2 * dxp[4]);
                 const double u1 = -dxp[1] + (z2 * dxp[3] - z0 * dxp[5]);
                 const double u2 = -dxp[2] + (z0 * dxp[4] - z1 * dxp[3]);
 #pragma unroll
-                for (int c = 0; c < 3; ++c)
-                    v[c] = ldp(d.NZ + c * E, eo) * u0 + ldp(d.NZ + (3 + c) * E, eo) * u1 + ldp(d.NZ + (6 + c) * E, eo) * u2;
+                for (int c = 0; c < 3; ++c) v[c] = nz[c] * u0 + nz[3 + c] * u1 + nz[6 + c] * u2;
             }
             s_v[0][tid] = v[0]; s_v[1][tid] = v[1]; s_v[2][tid] = v[2];
         }
