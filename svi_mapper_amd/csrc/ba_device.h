@@ -46,15 +46,13 @@ struct BaDev {
     const int*     e_pose;  // [E] pose slot
     const int*     e_lm;    // [E] landmark
     const uint8_t* e_flags; // [E]
-    const double*  e_z;     // [3][E]
-    const double*  e_info;  // [info_planes][E]
+    const double*  e_zi;    // [(3 + info_planes + 1) / 2][E] double2: z (3), information (info_planes), pad
     const int*     lm_ptr;  // [Ll+1] edges of landmark l
     const int*     lb_lm;   // [n_lm_blocks+1] landmarks of lm-major workgroup b
     // pose-major copy
     const int*     pm_lm;    // [E]
     const uint8_t* pm_flags; // [E]
-    const double*  pm_z;     // [3][E]
-    const double*  pm_info;  // [info_planes][E]
+    const double*  pm_zi;    // the same, pose-major order
     const int*     chunk_pose;  // [n_chunks] pose slot
     const int*     chunk_begin; // [n_chunks+1]
     const int*     pose_chunk_ptr; // [Pn+1] chunks of pose slot s

@@ -329,15 +329,17 @@ int build_structure(svi_ba* ba)
     static const int kDiagIdx[3] = {0, 3, 5};
     std::vector<int> e_pose(E), e_lm(E), e_orig(E), lm_ptr(Ll + 1, 0);
     std::vector<uint8_t> e_flags(E);
-    std::vector<double> e_z((size_t)3 * E), e_info((size_t)planes * E);
+    const int np2 = (3 + planes + 1) / 2; // double2 planes of the packed [z | information | pad] record
+    std::vector<double> e_zi((size_t)2 * np2 * std::max(E, 1), 0.0);
+    auto zi_at = [&](std::vector<double>& a, int v, int k) -> double& { return a[2 * ((size_t)(v / 2) * E + k) + (v & 1)]; };
     for (int k = 0; k < E; ++k) {
         const HProj& e = ba->proj[loc[k]];
         e_pose[k] = pose_slot[e.pose];
         e_lm[k] = lm_slot[e.lm] - L0;
         e_orig[k] = loc[k];
         e_flags[k] = (uint8_t)((e.type & 3) | (e.robust ? kFlagRobust : 0));
-        for (int c = 0; c < 3; ++c) e_z[(size_t)c * E + k] = e.z[c];
-        for (int c = 0; c < planes; ++c) e_info[(size_t)c * E + k] = diag_info ? e.info[kDiagIdx[c]] : e.info[c];
+        for (int c = 0; c < 3; ++c) zi_at(e_zi, c, k) = e.z[c];
+        for (int c = 0; c < planes; ++c) zi_at(e_zi, 3 + c, k) = diag_info ? e.info[kDiagIdx[c]] : e.info[c];
         lm_ptr[e_lm[k] + 1]++;
     }
     for (int l = 0; l < Ll; ++l) {
@@ -372,14 +374,13 @@ int build_structure(svi_ba* ba)
     const int Epm = (int)pm.size();
     std::vector<int> pm_lm(Epm), chunk_pose, chunk_begin, pose_chunk_ptr(Pn + 1, 0);
     std::vector<uint8_t> pm_flags(Epm);
-    // pose-major planes use the same plane stride E as the lm-major arrays (the kernels share load_edge)
-    std::vector<double> pm_z((size_t)3 * E), pm_info((size_t)planes * E);
+    // the pose-major copy uses the same plane stride E as the lm-major arrays (the kernels share load_edge)
+    std::vector<double> pm_zi((size_t)2 * np2 * std::max(E, 1), 0.0);
     for (int k = 0; k < Epm; ++k) {
         const int src = pm[k];
         pm_lm[k] = e_lm[src];
         pm_flags[k] = e_flags[src];
-        for (int c = 0; c < 3; ++c) pm_z[(size_t)c * E + k] = e_z[(size_t)c * E + src];
-        for (int c = 0; c < planes; ++c) pm_info[(size_t)c * E + k] = e_info[(size_t)c * E + src];
+        for (int v = 0; v < 3 + planes; ++v) zi_at(pm_zi, v, k) = zi_at(e_zi, v, src);
     }
     {
         int k = 0;
@@ -755,14 +756,12 @@ int build_structure(svi_ba* ba)
     SVI_TRY(dev_upload(ba, e_pose, &d.e_pose));
     SVI_TRY(dev_upload(ba, e_lm, &d.e_lm));
     SVI_TRY(dev_upload(ba, e_flags, &d.e_flags));
-    SVI_TRY(dev_upload(ba, e_z, &d.e_z));
-    SVI_TRY(dev_upload(ba, e_info, &d.e_info));
+    SVI_TRY(dev_upload(ba, e_zi, &d.e_zi));
     SVI_TRY(dev_upload(ba, lm_ptr, &d.lm_ptr));
     SVI_TRY(dev_upload(ba, lb_lm, &d.lb_lm));
     SVI_TRY(dev_upload(ba, pm_lm, &d.pm_lm));
     SVI_TRY(dev_upload(ba, pm_flags, &d.pm_flags));
-    SVI_TRY(dev_upload(ba, pm_z, &d.pm_z));
-    SVI_TRY(dev_upload(ba, pm_info, &d.pm_info));
+    SVI_TRY(dev_upload(ba, pm_zi, &d.pm_zi));
     SVI_TRY(dev_upload(ba, chunk_pose, &d.chunk_pose));
     SVI_TRY(dev_upload(ba, chunk_begin, &d.chunk_begin));
     SVI_TRY(dev_upload(ba, pose_chunk_ptr, &d.pose_chunk_ptr));

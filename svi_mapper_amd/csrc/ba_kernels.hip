@@ -156,18 +156,19 @@ __device__ __forceinline__ void stp2(double* __restrict__ nz, size_t E, int p, u
     *reinterpret_cast<double2*>(reinterpret_cast<char*>(nz + 2 * (size_t)p * E) + (size_t)(e * 16u)) = make_double2(a, b);
 }
 
+// measurement z (3) and information (diagonal: 3, else the 6 of the upper triangle) of an edge, packed in double2 planes
+// like N|2Z: [z0 z1][z2 i0][i1 i2]( [i3 i4][i5 -] )
 template <bool DIAG>
-__device__ __forceinline__ void load_edge(const double* __restrict__ zp, const double* __restrict__ ip,
-                                          const uint8_t* __restrict__ flags, int E, int e, EdgeIn& in)
+__device__ __forceinline__ void load_edge(const double* __restrict__ zi, const uint8_t* __restrict__ flags, int E, int e, EdgeIn& in)
 {
-    const unsigned off = (unsigned)e * 8u;
-    in.z[0] = ldp(zp, off); in.z[1] = ldp(zp + (size_t)E, off); in.z[2] = ldp(zp + 2 * (size_t)E, off);
+    const double2 x0 = ldp2(zi, (size_t)E, 0, (unsigned)e), x1 = ldp2(zi, (size_t)E, 1, (unsigned)e), x2 = ldp2(zi, (size_t)E, 2, (unsigned)e);
+    in.z[0] = x0.x; in.z[1] = x0.y; in.z[2] = x1.x;
     if (DIAG) {
-        in.info[0] = ldp(ip, off); in.info[3] = ldp(ip + (size_t)E, off); in.info[5] = ldp(ip + 2 * (size_t)E, off);
+        in.info[0] = x1.y; in.info[3] = x2.x; in.info[5] = x2.y;
         in.info[1] = 0.0; in.info[2] = 0.0; in.info[4] = 0.0;
     } else {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) in.info[k] = ldp(ip + (size_t)k * E, off);
+        const double2 x3 = ldp2(zi, (size_t)E, 3, (unsigned)e), x4 = ldp2(zi, (size_t)E, 4, (unsigned)e);
+        in.info[0] = x1.y; in.info[1] = x2.x; in.info[2] = x2.y; in.info[3] = x3.x; in.info[4] = x3.y; in.info[5] = x4.x;
     }
     const unsigned f = flags[e];
     in.type = f & kFlagTypeMask;
@@ -207,7 +208,7 @@ __device__ __forceinline__ void lm_fetch(const BaDev& d, int b, LmFetch<DIAG>& f
     f.nl = l1 - f.l0;
     f.e0 = d.lm_ptr[f.l0]; f.e1 = d.lm_ptr[l1];
     const int e = min(f.e0 + tid, f.e1 - 1);
-    load_edge<DIAG>(d.e_z, d.e_info, d.e_flags, d.E, e, f.in);
+    load_edge<DIAG>(d.e_zi, d.e_flags, d.E, e, f.in);
     f.s = d.e_pose[e]; f.l = d.e_lm[e];
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
@@ -406,7 +407,7 @@ __device__ __forceinline__ void sweep_pose_chunk(const BaDev& d, int cur, int c,
     for (int it = 0; it < U; ++it) li[it] = d.pm_lm[min(e0 + tid + it * kBlock, e1 - 1)];
     EdgeIn nxt;
     double pn[3];
-    load_edge<DIAG>(d.pm_z, d.pm_info, d.pm_flags, E, min(e0 + tid, e1 - 1), nxt);
+    load_edge<DIAG>(d.pm_zi, d.pm_flags, E, min(e0 + tid, e1 - 1), nxt);
 #pragma unroll
     for (int k = 0; k < 3; ++k) pn[k] = lm[3 * li[0] + k];
 #pragma unroll
@@ -414,7 +415,7 @@ __device__ __forceinline__ void sweep_pose_chunk(const BaDev& d, int cur, int c,
         const EdgeIn in = nxt;
         const double p[3] = {pn[0], pn[1], pn[2]};
         if (it + 1 < U) {
-            load_edge<DIAG>(d.pm_z, d.pm_info, d.pm_flags, E, min(e0 + tid + (it + 1) * kBlock, e1 - 1), nxt);
+            load_edge<DIAG>(d.pm_zi, d.pm_flags, E, min(e0 + tid + (it + 1) * kBlock, e1 - 1), nxt);
 #pragma unroll
             for (int k = 0; k < 3; ++k) pn[k] = lm[3 * li[it + 1] + k];
         }
@@ -1084,7 +1085,7 @@ __global__ __launch_bounds__(kBlock) void k_backsub_chi2(BaDev d, int cur, doubl
     __syncthreads();
     if (e < e1) {
         EdgeIn in;
-        load_edge<DIAG>(d.e_z, d.e_info, d.e_flags, (int)E, e, in);
+        load_edge<DIAG>(d.e_zi, d.e_flags, (int)E, e, in);
         const int ll = d.e_lm[e] - l0;
         double R[9], t[3];
 #pragma unroll
@@ -1150,8 +1151,8 @@ __global__ __launch_bounds__(kBlock) void k_debug_jacobians(BaDev d, int cur, co
     const int e = blockIdx.x * kBlock + threadIdx.x;
     if (e >= d.E) return;
     EdgeIn in;
-    if (d.info_planes == 3) load_edge<true>(d.e_z, d.e_info, d.e_flags, d.E, e, in);
-    else load_edge<false>(d.e_z, d.e_info, d.e_flags, d.E, e, in);
+    if (d.info_planes == 3) load_edge<true>(d.e_zi, d.e_flags, d.E, e, in);
+    else load_edge<false>(d.e_zi, d.e_flags, d.E, e, in);
     const int s = d.e_pose[e], l = d.e_lm[e];
     const double* pose = d.pose[cur];
     const double* lm = d.lm[cur];
