@@ -910,25 +910,45 @@ __global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
 __global__ __launch_bounds__(kBlock) void k_assemble(BaDev d)
 {
     __shared__ double s_t[48][49];
+    __shared__ double s_part[4][36 * 16];
     const int sub = blockIdx.x, tid = threadIdx.x;
     const int cx = d.sub_cx[sub], cy = d.sub_cy[sub], n = 6 * d.Pf, TS = d.TS;
     // slabs: wave w of this workgroup sums cell (u, v) = (w >> 1, w & 1) of the sub-tile.  A quarter job qj left its
     // [36][16] values at slab[(qj >> 2)][q][(qj & 3) * 16 + l16]: block (i, j) = (l16 >> 2, l16 & 3), entry (q / 6, q % 6).
     {
-        constexpr int NE = 36 * 16 / 64; // 9 elements per lane, all in flight for every quarter job (summed in list order)
+        constexpr int NE = 36 * 16 / 64; // 9 elements per lane, all in flight for every quarter job
         const int w = tid >> 6, lane = tid & 63, u = w >> 1, vv = w & 1;
-        const int cell = 4 * sub + w;
+        // A hot cell can have twenty quarter jobs and its neighbours none: the four waves share the jobs of EVERY cell
+        // (wave w takes the jobs w, w+4, ... of the cell's list), the four partials meet in LDS and are added in wave
+        // order by the wave that owns the cell - a fixed order, so the result stays reproducible.
         double v[NE];
 #pragma unroll
         for (int k = 0; k < NE; ++k) v[k] = 0.0;
-        for (int x = d.cell_qj_ptr[cell]; x < d.cell_qj_ptr[cell + 1]; ++x) {
-            const int qj = d.cell_qj[x];
-            const double* sl = d.slab + (size_t)(qj >> 2) * 36 * 64 + (qj & 3) * 16;
-            double wv[NE];
+        for (int c = 0; c < 4; ++c) {
+            const int cell = 4 * sub + c;
+            double pv[NE];
 #pragma unroll
-            for (int k = 0; k < NE; ++k) { const int e = lane + 64 * k; wv[k] = sl[(e >> 4) * 64 + (e & 15)]; }
+            for (int k = 0; k < NE; ++k) pv[k] = 0.0;
+            for (int x = d.cell_qj_ptr[cell] + w; x < d.cell_qj_ptr[cell + 1]; x += 4) {
+                const int qj = d.cell_qj[x];
+                const double* sl = d.slab + (size_t)(qj >> 2) * 36 * 64 + (qj & 3) * 16;
+                double wv[NE];
 #pragma unroll
-            for (int k = 0; k < NE; ++k) v[k] -= wv[k];
+                for (int k = 0; k < NE; ++k) { const int e = lane + 64 * k; wv[k] = sl[(e >> 4) * 64 + (e & 15)]; }
+#pragma unroll
+                for (int k = 0; k < NE; ++k) pv[k] -= wv[k];
+            }
+            if (d.cell_qj_ptr[cell + 1] - d.cell_qj_ptr[cell] > 0) { // block-uniform
+#pragma unroll
+                for (int k = 0; k < NE; ++k) s_part[w][lane + 64 * k] = pv[k];
+                __syncthreads();
+                if (w == c) {
+#pragma unroll
+                    for (int k = 0; k < NE; ++k)
+                        v[k] = ((s_part[0][lane + 64 * k] + s_part[1][lane + 64 * k]) + s_part[2][lane + 64 * k]) + s_part[3][lane + 64 * k];
+                }
+                __syncthreads();
+            }
         }
 #pragma unroll
         for (int k = 0; k < NE; ++k) {
