@@ -1019,13 +1019,16 @@ __global__ __launch_bounds__(kBlock) void k_assemble(BaDev d)
 // ---------------------------------------------------------------------------------------------
 // K7 (poses): trial pose = pose [+] dx (g2o VertexSE3::oplusImpl); pose part of g2o's computeScale.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_update_poses(BaDev d, int cur, double lambda)
+__global__ __launch_bounds__(kRedThreads) void k_update_poses(BaDev d, int cur, double lambda)
 {
-    __shared__ double s_red[4];
+    // one workgroup (the step scale is a single sum), but wide: with 1024 threads a trajectory of up to 1024 poses is one
+    // pass of "index, then operands" round trips instead of several
+    constexpr int NW = kRedThreads / 64;
+    __shared__ double s_red[NW];
     const double* __restrict__ src = d.pose[cur];
     double* __restrict__ dst = d.pose[cur ^ 1];
     double part[1] = {0.0};
-    for (int s = threadIdx.x; s < d.Pn; s += kBlock) {
+    for (int s = threadIdx.x; s < d.Pn; s += kRedThreads) {
         const int r = d.pose_red[s];
         if (r < 0) {
             for (int k = 0; k < 12; ++k) dst[12 * s + k] = src[12 * s + k];
@@ -1035,7 +1038,7 @@ __global__ __launch_bounds__(kBlock) void k_update_poses(BaDev d, int cur, doubl
             pose_oplus(src + 12 * s, dl, dst + 12 * s);
         }
     }
-    block_sum<1>(part, s_red);
+    block_sum<1, NW>(part, s_red);
     if (threadIdx.x == 0) d.scal[3] = part[0];
 }
 
@@ -1263,7 +1266,7 @@ void ba_assemble(const BaDev& d, void* st)
 }
 void ba_update_poses(const BaDev& d, int cur, double lambda, void* st)
 {
-    hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(kBlock), 0, S_(st), d, cur, lambda);
+    hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(kRedThreads), 0, S_(st), d, cur, lambda);
 }
 void ba_backsub_chi2(const BaDev& d, int cur, double lambda, void* st)
 {
