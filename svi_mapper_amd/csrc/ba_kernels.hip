@@ -26,31 +26,7 @@ constexpr int kBlock = 256;
 // ---------------------------------------------------------------------------------------------
 // block-wide sum of NV doubles held by every thread; result valid in thread 0. Fixed order.
 template <int NV, int NW = 4>
-__device__ __forceinline__ void block_sum(double (&v)[NV], double* s_red /* [NV][NW] */)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < NV; ++k) {
-        double x = v[k];
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
-        if (lane == 0) s_red[k * NW + wave] = x;
-    }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            if (NW == 4) v[k] = (s_red[k * 4] + s_red[k * 4 + 1]) + (s_red[k * 4 + 2] + s_red[k * 4 + 3]);
-            else {
-                double t = s_red[k * NW];
-#pragma unroll
-                for (int w = 1; w < NW; ++w) t += s_red[k * NW + w];
-                v[k] = t;
-            }
-        }
-    }
-    __syncthreads();
-}
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* s_red /* [NV][NW] */);
 
 template <int NW = 4>
 __device__ __forceinline__ double block_max(double x, double* s_red /* [NW] */)
@@ -123,6 +99,40 @@ __device__ __forceinline__ double wave_max(double x)
     x = fmax(x, dpp_mov<0x122>(x));
     x = fmax(x, dpp_mov<0x121>(x));
     return fmax(fmax(readlane_f64(x, 0), readlane_f64(x, 16)), fmax(readlane_f64(x, 32), readlane_f64(x, 48)));
+}
+
+template <int NV, int NW>
+__device__ __forceinline__ void block_sum(double (&v)[NV], double* s_red /* [NV][NW] */)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (NW == 4) { // the 256-thread kernels: shuffle tree per wave, the four wave sums added pairwise by thread 0
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            double x = v[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) x += __shfl_down(x, off, 64);
+            if (lane == 0) s_red[k * 4 + wave] = x;
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[k] = (s_red[k * 4] + s_red[k * 4 + 1]) + (s_red[k * 4 + 2] + s_red[k * 4 + 3]);
+        }
+        __syncthreads();
+    } else { // the 1024-thread reducers: DPP inside the wave, then the 16 wave sums by one DPP row of wave 0
+        static_assert(NW == 4 || NW == 16, "block_sum: 4 or 16 waves");
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const double x = wave_sum(v[k]);
+            if (lane == 0) s_red[k * NW + wave] = x;
+        }
+        __syncthreads();
+        if (wave == 0) {
+#pragma unroll
+            for (int k = 0; k < NV; ++k) v[k] = row16_sum(s_red[k * NW + (lane & 15)]); // valid in every lane of wave 0
+        }
+        __syncthreads();
+    }
 }
 
 struct EdgeIn {
