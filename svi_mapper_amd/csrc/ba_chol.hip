@@ -144,7 +144,7 @@ constexpr int kPotrfThreads = 512;
 // ---------------------------------------------------------------------------------------------
 template <int TS>
 __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, double* __restrict__ Lg, double* sL, double* sX,
-                                                 double (*s_col)[4][TS], double* s_rs, int k, int n, double lambda, int stop_after,
+                                                 double (*s_col)[TS][4], double* s_rs, int k, int n, double lambda, int stop_after,
                                                  double* __restrict__ y, const double* __restrict__ Lt, const int* __restrict__ pre_tile,
                                                  const int* __restrict__ pre_col, int npre, double* s_g)
 {
@@ -225,13 +225,13 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
     for (int jb = 0; jb < NB; ++jb) {
         for (int jq = 0; jq < 16 / KB; ++jq) {
             const int jx = KB * jq, j = 16 * jb + jx;
-            double (*col)[TS] = s_col[jq & 1];
+            double (*col)[4] = s_col[jq & 1]; // [row][pivot of the quad]: the four values of a row are one 32-byte read
             // the four columns of the quad, from the blocks of block column jb
 #pragma unroll
             for (int u = 0; u < PER; ++u)
                 if (own[u] && bb[u] == jb && (ln >> 2) == jq) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) col[ln & 3][16 * ba[u] + lk + 4 * q] = acc[u][q];
+                    for (int q = 0; q < 4; ++q) col[16 * ba[u] + lk + 4 * q][ln & 3] = acc[u][q];
                 }
             __syncthreads();
             // KB x KB pivot block, LDL' in registers (every lane redundantly)
@@ -240,7 +240,7 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
             for (int m = 0; m < KB; ++m) {
 #pragma unroll
                 for (int q = 0; q <= m; ++q) {
-                    double v = col[q][j + m];
+                    double v = col[j + m][q];
 #pragma unroll
                     for (int t = 0; t < q; ++t) v = fma(-w[m][t], l[q][t], v);
                     w[m][q] = v;
@@ -267,8 +267,9 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
             for (int u = 0; u < PER; ++u)
                 if (own[u] && bb[u] >= jb) {
                     const int ra = 16 * ba[u] + ln, rb = 16 * bb[u] + ln;
-                    const double a0 = col[0][ra], a1 = col[1][ra], a2 = col[2][ra], a3 = col[3][ra];
-                    const double b0 = col[0][rb], b1 = col[1][rb], b2 = col[2][rb], b3 = col[3][rb];
+                    const double2 a01 = *reinterpret_cast<const double2*>(&col[ra][0]), a23 = *reinterpret_cast<const double2*>(&col[ra][2]);
+                    const double2 b01 = *reinterpret_cast<const double2*>(&col[rb][0]), b23 = *reinterpret_cast<const double2*>(&col[rb][2]);
+                    const double a0 = a01.x, a1 = a01.y, a2 = a23.x, a3 = a23.y, b0 = b01.x, b1 = b01.y, b2 = b23.x, b3 = b23.y;
                     const double wa = fma(ca1, a1, ca0 * a0) + fma(ca3, a3, ca2 * a2); // = -w[lk] / d[lk] at row ra
                     const double wb = fma(cl1, b1, cl0 * b0) + fma(cl3, b3, cl2 * b2); // =  w[lk]         at row rb
                     // rows / columns up to the pivot stay as they are (in block row / column jb only)
@@ -344,13 +345,13 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
     extern __shared__ __align__(16) double sm[];
     double* sL = sm;            // [TS][LD]
     double* sX = sm + TS * LD;  // [TS][LD]
-    // scratch of the pivot sweep: the published columns, [parity][column of the quad][row]
+    // scratch of the pivot sweep: the published columns, [parity][row][column of the quad]
     constexpr int kScratch = 2 * 4 * TS;
-    __shared__ double s_buf[kScratch];
+    __shared__ __align__(16) double s_buf[kScratch];
     __shared__ double s_rs[TS];        // 1/sqrt(d_j) = 1/L_jj
     __shared__ double s_g[TS];
     static_assert(sizeof(double) * (2 * TS * LD + kScratch + 2 * TS) <= 160 * 1024, "potrf LDS budget (160 KiB per workgroup)");
-    double (*s_col)[4][TS] = reinterpret_cast<double (*)[4][TS]>(s_buf);
+    double (*s_col)[TS][4] = reinterpret_cast<double (*)[TS][4]>(s_buf);
     const int tid = threadIdx.x;
     const int failed = *status; // tested together with the column record: one round trip, not two
     const int4 ds = sa.chain_desc[2 * ((int)blockIdx.x < sa.n_chain ? (int)blockIdx.x : 0)];
