@@ -675,13 +675,13 @@ int build_structure(svi_ba* ba)
     for (int i = 0; i < n_items; ++i) {
         it_pack[4 * i] = items[i].lm; it_pack[4 * i + 1] = items[i].a0; it_pack[4 * i + 2] = items[i].b0; it_pack[4 * i + 3] = items[i].masks;
     }
-    // quarter jobs: about one wavefront job per SIMD of the chip.  Measured at config 4: the kernel takes the same
-    // 240-247 us from 3500 to 8192 quarter jobs (it is bound by instructions per pass, not by occupancy), while the
-    // assemble kernel's time grows with the number of slabs.
+    // quarter jobs: as many as fit on the chip at once - the kernel holds two waves per SIMD (214 VGPRs, 59 KB of LDS
+    // per workgroup), one more would wait for a whole round.  Measured at config 4 with the current kernels (quarter
+    // jobs: Schur + assemble us): 4096: 207 + 22, 6144: 185 + 27, 8192: 176 + 33, 10240: 209 + 38.
     const int n_cells = 4 * n_sub;
     int n_cu = 256;
     { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ba->opt.device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
-    const int64_t qj_cap = (int64_t)4 * (n_cu * 4);
+    const int64_t qj_cap = (int64_t)4 * (n_cu * 4 * 2);
     std::vector<int> cell_count;
     for (int i = 0; i < n_items;) { int j = i; while (j < n_items && items[j].cell == items[i].cell) ++j; cell_count.push_back(j - i); i = j; }
     auto pieces = [&](int len) { int64_t n = 0; for (int c : cell_count) n += (c + len - 1) / len; return n; };
