@@ -1001,25 +1001,40 @@ __global__ __launch_bounds__(kBlock) void k_assemble(BaDev d)
         out[(size_t)r * TS + c] = v;
     }
     if (cx == cy) {
+        // right-hand side: row r of the sub-tile collects the g slabs of its diagonal cell.  Five threads per row share
+        // the list (thread part takes entries part, part+5, ..., four in flight), their partials meet in LDS and are
+        // added in part order - a hot cell has forty quarter jobs, one thread per row walked them for 8 us.
+        constexpr int GP = 5;
+        static_assert(GP * 48 <= kBlock && GP * 48 <= 4 * 36 * 16, "g partial buffer");
+        double* s_gp = &s_part[0][0]; // [GP][48], the slab partials are long done
+        __syncthreads();
+        if (tid < GP * 48) {
+            const int part = tid / 48, r = tid % 48, row = R0 + r;
+            double v = 0.0;
+            if (row < n) {
+                const int pl = r / 6, cell = 4 * sub + 3 * (pl >> 2); // diagonal cell (u, u) of the row's pose
+                const int x1 = d.cell_qj_ptr[cell + 1];
+                for (int x = d.cell_qj_ptr[cell] + part; x < x1; x += 4 * GP) {
+                    int q4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) q4[i] = d.cell_qj[min(x + GP * i, x1 - 1)];
+                    double g4[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) g4[i] = d.gslab[((size_t)q4[i] * 6 + r % 6) * 4 + (pl & 3)];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) if (x + GP * i < x1) v -= g4[i];
+                }
+            }
+            s_gp[part * 48 + r] = v;
+        }
+        __syncthreads();
         for (int r = tid; r < 48; r += kBlock) {
             const int row = R0 + r;
             double v = 0.0;
             if (row < n) {
                 if (d.add_pose_terms) v = d.bp[row];
-                const int pl = r / 6, cell = 4 * sub + 3 * (pl >> 2); // diagonal cell (u, u) of the row's pose
-                // four list entries per step, ids and values in flight together (a hot cell has twenty quarter jobs:
-                // one at a time this loop was 9 us of the workgroup's 22); the subtractions keep the list order
-                const int x1 = d.cell_qj_ptr[cell + 1];
-                for (int x = d.cell_qj_ptr[cell]; x < x1; x += 4) {
-                    int q4[4];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i) q4[i] = d.cell_qj[min(x + i, x1 - 1)];
-                    double g4[4];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) g4[i] = d.gslab[((size_t)q4[i] * 6 + r % 6) * 4 + (pl & 3)];
-#pragma unroll
-                    for (int i = 0; i < 4; ++i) if (x + i < x1) v -= g4[i];
-                }
+                for (int part = 0; part < GP; ++part) v += s_gp[part * 48 + r];
             }
             d.g[row] = v;
         }
