@@ -917,10 +917,13 @@ __global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
 // blocks) minus the quarter-job slabs of its four cells, summed in a fixed order, written into its tile.
 // Diagonal sub-tiles also assemble their part of g and the identity padding of the last rows.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_assemble(BaDev d)
+constexpr int kAsmThreads = 512; // eight waves: the quarter-job slabs of a cell are shared by all of them
+
+__global__ __launch_bounds__(kAsmThreads) void k_assemble(BaDev d)
 {
     __shared__ double s_t[48][49];
-    __shared__ double s_part[4][36 * 16];
+    constexpr int NWA = kAsmThreads / 64;
+    __shared__ double s_part[NWA][36 * 16];
     const int sub = blockIdx.x, tid = threadIdx.x;
     const int cx = d.sub_cx[sub], cy = d.sub_cy[sub], n = 6 * d.Pf, TS = d.TS;
     // slabs: wave w of this workgroup sums cell (u, v) = (w >> 1, w & 1) of the sub-tile.  A quarter job qj left its
@@ -928,8 +931,8 @@ __global__ __launch_bounds__(kBlock) void k_assemble(BaDev d)
     {
         constexpr int NE = 36 * 16 / 64; // 9 elements per lane, all in flight for every quarter job
         const int w = tid >> 6, lane = tid & 63, u = w >> 1, vv = w & 1;
-        // A hot cell can have twenty quarter jobs and its neighbours none: the four waves share the jobs of EVERY cell
-        // (wave w takes the jobs w, w+4, ... of the cell's list), the four partials meet in LDS and are added in wave
+        // A hot cell can have forty quarter jobs and its neighbours none: the eight waves share the jobs of EVERY cell
+        // (wave w takes the jobs w, w+8, ... of the cell's list), the partials meet in LDS and are added in wave
         // order by the wave that owns the cell - a fixed order, so the result stays reproducible.
         double v[NE];
 #pragma unroll
@@ -940,9 +943,9 @@ __global__ __launch_bounds__(kBlock) void k_assemble(BaDev d)
 #pragma unroll
             for (int k = 0; k < NE; ++k) pv[k] = 0.0;
             const int xe = d.cell_qj_ptr[cell + 1];
-            for (int x = d.cell_qj_ptr[cell] + w; x < xe; x += 8) { // two of this wave's jobs per step: 18 loads in flight
-                const bool two = x + 4 < xe;
-                const int qa = d.cell_qj[x], qb = d.cell_qj[two ? x + 4 : x];
+            for (int x = d.cell_qj_ptr[cell] + w; x < xe; x += 2 * NWA) { // two of this wave's jobs per step: 18 loads in flight
+                const bool two = x + NWA < xe;
+                const int qa = d.cell_qj[x], qb = d.cell_qj[two ? x + NWA : x];
                 const double* sa = d.slab + (size_t)(qa >> 2) * 36 * 64 + (qa & 3) * 16;
                 const double* sb = d.slab + (size_t)(qb >> 2) * 36 * 64 + (qb & 3) * 16;
                 double wa[NE], wb[NE];
@@ -957,22 +960,28 @@ __global__ __launch_bounds__(kBlock) void k_assemble(BaDev d)
                 __syncthreads();
                 if (w == c) {
 #pragma unroll
-                    for (int k = 0; k < NE; ++k)
-                        v[k] = ((s_part[0][lane + 64 * k] + s_part[1][lane + 64 * k]) + s_part[2][lane + 64 * k]) + s_part[3][lane + 64 * k];
+                    for (int k = 0; k < NE; ++k) {
+                        double t = s_part[0][lane + 64 * k];
+#pragma unroll
+                        for (int ww = 1; ww < NWA; ++ww) t += s_part[ww][lane + 64 * k];
+                        v[k] = t;
+                    }
                 }
                 __syncthreads();
             }
         }
+        if (w < 4) { // the waves that own a cell (u, v) = (w >> 1, w & 1)
 #pragma unroll
-        for (int k = 0; k < NE; ++k) {
-            const int e = lane + 64 * k, q = e >> 4, l16 = e & 15;
-            s_t[(4 * u + (l16 >> 2)) * 6 + q / 6][(4 * vv + (l16 & 3)) * 6 + q % 6] = v[k];
+            for (int k = 0; k < NE; ++k) {
+                const int e = lane + 64 * k, q = e >> 4, l16 = e & 15;
+                s_t[(4 * u + (l16 >> 2)) * 6 + q / 6][(4 * vv + (l16 & 3)) * 6 + q % 6] = v[k];
+            }
         }
     }
     __syncthreads();
     if (d.add_pose_terms) {
         if (cx == cy) {
-            for (int e = tid; e < 8 * 36; e += kBlock) {
+            for (int e = tid; e < 8 * 36; e += kAsmThreads) {
                 const int pl = e / 36, rr = (e % 36) / 6, cc = e % 6;
                 const int r = cx * 8 + pl;
                 if (r < d.Pf) {
@@ -982,7 +991,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble(BaDev d)
             }
         }
         __syncthreads();
-        for (int e = d.sub_aux_ptr[sub] * 36 + tid; e < d.sub_aux_ptr[sub + 1] * 36; e += kBlock) {
+        for (int e = d.sub_aux_ptr[sub] * 36 + tid; e < d.sub_aux_ptr[sub + 1] * 36; e += kAsmThreads) {
             const int ref = d.sub_aux_ref[e / 36], k = ref >> 1, tr = ref & 1;
             const int rr = (e % 36) / 6, cc = e % 6;
             const int ri = d.pose_red[d.se3_i[k]], rj = d.pose_red[d.se3_j[k]];
@@ -994,7 +1003,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble(BaDev d)
     }
     const int R0 = cx * 48, C0 = cy * 48;
     double* out = d.S + (size_t)d.sub_tile[sub] * TS * TS + (size_t)(R0 % TS) * TS + (C0 % TS);
-    for (int e = tid; e < 48 * 48; e += kBlock) {
+    for (int e = tid; e < 48 * 48; e += kAsmThreads) {
         const int r = e / 48, c = e % 48;
         double v = s_t[r][c];
         if (R0 + r >= n || C0 + c >= n) v = (R0 + r == C0 + c) ? 1.0 : 0.0; // identity padding
@@ -1005,7 +1014,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble(BaDev d)
         // the list (thread part takes entries part, part+5, ..., four in flight), their partials meet in LDS and are
         // added in part order - a hot cell has forty quarter jobs, one thread per row walked them for 8 us.
         constexpr int GP = 5;
-        static_assert(GP * 48 <= kBlock && GP * 48 <= 4 * 36 * 16, "g partial buffer");
+        static_assert(GP * 48 <= kAsmThreads && GP * 48 <= NWA * 36 * 16, "g partial buffer");
         double* s_gp = &s_part[0][0]; // [GP][48], the slab partials are long done
         __syncthreads();
         if (tid < GP * 48) {
@@ -1028,7 +1037,7 @@ __global__ __launch_bounds__(kBlock) void k_assemble(BaDev d)
             s_gp[part * 48 + r] = v;
         }
         __syncthreads();
-        for (int r = tid; r < 48; r += kBlock) {
+        for (int r = tid; r < 48; r += kAsmThreads) {
             const int row = R0 + r;
             double v = 0.0;
             if (row < n) {
@@ -1291,7 +1300,7 @@ void ba_schur(const BaDev& d, void* st)
 }
 void ba_assemble(const BaDev& d, void* st)
 {
-    if (d.n_sub > 0) hipLaunchKernelGGL(k_assemble, dim3(d.n_sub), dim3(kBlock), 0, S_(st), d);
+    if (d.n_sub > 0) hipLaunchKernelGGL(k_assemble, dim3(d.n_sub), dim3(kAsmThreads), 0, S_(st), d);
 }
 void ba_update_poses(const BaDev& d, int cur, double lambda, void* st)
 {
