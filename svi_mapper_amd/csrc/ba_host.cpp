@@ -954,6 +954,20 @@ int linearize(svi_ba* ba, bool read = true)
     ba_pose_finalize(d, ba->red_slot, ba->opt.rank, ba->opt.n_ranks, s);
     t.end(s);
     SVI_HIP(hipGetLastError());
+    if (ba->side && !read && ba->ar) {
+        // nobody needs the summed pose blocks before k_assemble: the collective (latency bound at this size) and the
+        // kernel behind it go to the side stream and run beside the landmark inversion and the Schur products; trial()
+        // joins the two streams in front of k_assemble
+        SVI_HIP(hipEventRecord(ba->ev_fork, s));
+        SVI_HIP(hipStreamWaitEvent(ba->side, ba->ev_fork, 0));
+        const int rc = ba->ar(ba->ar_user, d.lin_buf, (size_t)d.lin_count, ba->side);
+        if (rc != 0) return fail(SVI_ERR_COMM, "all-reduce hook returned %d", rc);
+        ba_lin_post(d, ba->opt.n_ranks, ba->side);
+        SVI_HIP(hipEventRecord(ba->ev_join, ba->side));
+        SVI_HIP(hipGetLastError());
+        ba->lin_pending = true;
+        return SVI_OK;
+    }
     SVI_TRY(allreduce(ba, d.lin_buf, (size_t)d.lin_count));
     ba_lin_post(d, ba->opt.n_ranks, s);
     SVI_HIP(hipGetLastError());
@@ -972,6 +986,7 @@ int trial(svi_ba* ba, double lambda, bool* failed)
     ba_invert_landmarks(d, lambda, s);
     ba_schur(d, s);
     t.end(s);
+    if (ba->lin_pending) { SVI_HIP(hipStreamWaitEvent(s, ba->ev_join, 0)); ba->lin_pending = false; }
     t.begin(SVI_PH_ASSEMBLE, s); ba_assemble(d, s); t.end(s);
     SVI_HIP(hipGetLastError());
     SVI_TRY(allreduce(ba, d.g, (size_t)d.red_count));
@@ -1128,6 +1143,13 @@ int svi_ba_create(const svi_ba_options* o, svi_ba** out)
         if (e != hipSuccess) { delete ba; return fail(SVI_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         ba->own_stream = true;
     }
+    const char* ov = getenv("SVI_LIN_OVERLAP"); // 0: keep every collective on the main stream (A/B switch)
+    if (o->n_ranks > 1 && !(ov && ov[0] == '0')) {
+        hipError_t e = hipStreamCreateWithFlags(&ba->side, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ba->ev_fork, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&ba->ev_join, hipEventDisableTiming);
+        if (e != hipSuccess) { svi_ba_destroy(ba); return fail(SVI_ERR_HIP, "side stream: %s", hipGetErrorString(e)); }
+    }
     ba->timer.on = o->profile != 0;
     *out = ba;
     return SVI_OK;
@@ -1138,6 +1160,9 @@ int svi_ba_destroy(svi_ba* ba)
     if (!ba) return SVI_OK;
     (void)hipSetDevice(ba->opt.device);
     (void)hipStreamSynchronize(ba->stream);
+    if (ba->side) { (void)hipStreamSynchronize(ba->side); (void)hipStreamDestroy(ba->side); }
+    if (ba->ev_fork) (void)hipEventDestroy(ba->ev_fork);
+    if (ba->ev_join) (void)hipEventDestroy(ba->ev_join);
     free_device(ba);
     ba->timer.release();
     if (ba->own_stream) (void)hipStreamDestroy(ba->stream);
