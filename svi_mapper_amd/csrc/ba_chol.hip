@@ -314,6 +314,7 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
 // one 48x48 block of S(c) -= L(a) L(b)' by a 512-thread workgroup (defined below)
 struct StepArgs {
     int n_chain;                 // workgroups 0..n_chain-1 factorise one column each, the rest run grouped updates
+    int last_level;              // nothing is eliminated after these columns: they finish x_k themselves
     const int* chain_col;        // [n_chain] tile columns of this level
     const int4* chain_desc;      // [n_chain] pairs of int4: {column, diagonal tile, first pre, #pre}, {first sub-diagonal tile, #, 0, 0}
     const int* diag_tile;        // [NT]
@@ -436,7 +437,25 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
             a2 = fma(sX[tid * LD + c + 2], s_g[c + 2], a2);
             a3 = fma(sX[tid * LD + c + 3], s_g[c + 3], a3);
         }
-        y[k * TS + tid] = (a0 + a1) + (a2 + a3);
+        const double yk = (a0 + a1) + (a2 + a3);
+        if (!sa.last_level) y[k * TS + tid] = yk;
+        else s_rs[tid] = yk; // (1/L_jj is no longer needed)
+    }
+    if (sa.last_level) {
+        // the columns of the last level have no rows below them: x_k = L_kk^-T y_k needs nothing else, and the backward
+        // substitution starts one level (one launch on the critical path) further down
+        __syncthreads();
+        if (tid < TS) {
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 6
+            for (int r = 0; r < TS; r += 4) { // X is zero above the diagonal
+                a0 = fma(sX[r * LD + tid], s_rs[r], a0);
+                a1 = fma(sX[(r + 1) * LD + tid], s_rs[r + 1], a1);
+                a2 = fma(sX[(r + 2) * LD + tid], s_rs[r + 2], a2);
+                a3 = fma(sX[(r + 3) * LD + tid], s_rs[r + 3], a3);
+            }
+            y[k * TS + tid] = (a0 + a1) + (a2 + a3);
+        }
     }
 }
 
@@ -663,13 +682,13 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
     for (int st = 0; st < p.n_steps; ++st) {
         const int c0 = p.h_step_ptr[st], nc = p.h_step_ptr[st + 1] - c0;
         const int t0 = p.h_tgt_ptr[st], ntg = p.h_tgt_ptr[st + 1] - t0;
-        sa.n_chain = nc; sa.chain_col = p.step_col + c0; sa.chain_desc = reinterpret_cast<const int4*>(p.step_desc) + 2 * c0;
+        sa.n_chain = nc; sa.last_level = st == p.n_steps - 1; sa.chain_col = p.step_col + c0; sa.chain_desc = reinterpret_cast<const int4*>(p.step_desc) + 2 * c0;
         sa.tgt_tile = p.tgt_tile + t0; sa.tgt_row = p.tgt_row + t0; sa.tgt_pair_ptr = p.tgt_pair_ptr + t0;
         hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(nc + ntg * Q * Q), dim3(kPotrfThreads), lds_p, s, S, Lt, Linv, g, x, n, lambda, status, 0, sa);
         const int i0 = p.h_trsm_ptr[st], ni = p.h_trsm_ptr[st + 1] - i0;
         if (ni > 0) hipLaunchKernelGGL(k_trsm<TS>, dim3(ni * QT * QT), dim3(kBlock), lds_g, s, S, Lt, Linv, p.st_tile + i0, p.st_col + i0, status);
     }
-    for (int st = p.n_steps - 1; st >= 0; --st) {
+    for (int st = p.n_steps - 2; st >= 0; --st) { // (the last level solved its x inside k_potrf_inv)
         const int c0 = p.h_step_ptr[st], nc = p.h_step_ptr[st + 1] - c0;
         hipLaunchKernelGGL(k_back_solve<TS>, dim3(nc), dim3(kPotrfThreads), 0, s, Lt, Linv, x, p, reinterpret_cast<const int4*>(p.step_desc) + 2 * c0, status);
     }
