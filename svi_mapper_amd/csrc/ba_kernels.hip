@@ -669,6 +669,8 @@ __global__ __launch_bounds__(kRedThreads) void k_lin_post(BaDev d, int n_ranks)
     __shared__ double s_red[2 * NW];
     double mx = 0.0;
     double part[2] = {0.0, 0.0};
+    // the sums of the pose-only edges (or, with several ranks, the exchanged totals): fetched first, used last
+    const double t0 = SINGLE ? d.scal[6] : d.lin_scal[0], t1 = SINGLE ? d.scal[7] : d.lin_scal[1];
     if (SINGLE) for_each_part(d.block_part, 4 * d.n_lm_blocks, [&](const Part4& e) { part[0] += e.v[0]; part[1] += e.v[1]; mx = fmax(mx, e.v[2]); });
     for (int i = threadIdx.x; i < d.Pf * 6; i += kRedThreads) {
         const int r = i / 6, a = i % 6;
@@ -681,7 +683,7 @@ __global__ __launch_bounds__(kRedThreads) void k_lin_post(BaDev d, int n_ranks)
     // slots 8..10 carry the same numbers and survive the trial kernels (which rewrite 0..3): the host may pick them up
     // together with the trial results instead of waiting here
     if (threadIdx.x == 0) {
-        const double c0 = SINGLE ? part[0] + d.scal[6] : d.lin_scal[0], c1 = SINGLE ? part[1] + d.scal[7] : d.lin_scal[1];
+        const double c0 = SINGLE ? part[0] + t0 : t0, c1 = SINGLE ? part[1] + t1 : t1;
         d.scal[5] = mx; d.scal[0] = c0; d.scal[1] = c1;
         d.scal[8] = c0; d.scal[9] = c1; d.scal[10] = mx;
     }
@@ -1208,15 +1210,28 @@ __global__ __launch_bounds__(kRedThreads) void k_reduce_trial(BaDev d, int n_pub
     constexpr int NW = kRedThreads / 64;
     __shared__ double s_red[3 * NW];
     double part[3] = {0.0, 0.0, 0.0};
+    // what thread 0 adds or passes on at the end (written by earlier launches): fetched before the reduction, not after
+    // it as one more dependent round trip
+    double pre[12];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) pre[i] = d.scal[i];
+    const int st = *d.chol_status;
     for_each_part(d.block_part, 4 * d.n_lm_blocks, [&](const Part4& e) { part[0] += e.v[0]; part[1] += e.v[1]; part[2] += e.v[2]; });
     block_sum<3, NW>(part, s_red);
     if (threadIdx.x == 0) {
-        double fresh[3] = {part[0] + d.scal[6], part[1] + d.scal[7], part[2]};
+        double fresh[3] = {part[0] + pre[6], part[1] + pre[7], part[2]};
         // several ranks: a rank whose own landmark blocks or factorisation failed must fail the trial everywhere -
         // its chi2 goes out as +inf, which survives the sum of the all-reduce (ba_host.cpp trial())
-        if (n_pub == 0 && *d.chol_status != 0) fresh[0] = __builtin_inf();
+        if (n_pub == 0 && st != 0) fresh[0] = __builtin_inf();
         d.scal[0] = fresh[0]; d.scal[1] = fresh[1]; d.scal[2] = fresh[2];
-        if (n_pub > 0) publish_scalars(d.scal, n_pub, d.chol_status, h_scal, h_status, seq, fresh, 3);
+        if (n_pub > 0) {
+#pragma unroll
+            for (int i = 0; i < 12; ++i)
+                if (i < n_pub) __hip_atomic_store(h_scal + i, i < 3 ? fresh[i] : pre[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            __hip_atomic_store(h_status, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            *d.chol_status = 0;
+            __hip_atomic_store(h_status + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
     }
 }
 
