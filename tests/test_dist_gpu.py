@@ -152,3 +152,57 @@ def test_rccl_hook_aliases_library_memory(svi):
         assert torch.equal(x.cpu(), torch.arange(1000, dtype=torch.float64) + 1.0)
     finally:
         dist.destroy_process_group()
+
+
+def test_side_stream_collective_under_rccl(svi):
+    """Shard 0 of 2 driven through a real RCCL communicator (1 rank: every sum is the identity, so the handle solves
+    the sub-problem of its own landmarks): the all-reduce of the linearisation sums runs on the library's side stream
+    beside the Schur kernels. With the overlap switched off (SVI_LIN_OVERLAP=0) the same kernels and collectives run
+    on one stream - the results must be bit-identical, and nothing may hang."""
+    import os
+    import socket
+
+    import torch
+    import torch.distributed as dist
+
+    from svi_mapper_amd import dist as sdist
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    prob = synth.make_ba_problem(40, 3000, 20000, seed=5)
+    cam = prob["cam"]
+    out = {}
+    old = os.environ.get("SVI_LIN_OVERLAP")
+    try:
+        for overlap in ("1", "0"):
+            os.environ["SVI_LIN_OVERLAP"] = overlap
+            streams = set()
+            inner = sdist.make_allreduce_hook()
+
+            def hook(ptr, count, stream, inner=inner, streams=streams):
+                streams.add(stream)
+                return inner(ptr, count, stream)
+
+            ba = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"], rank=0, n_ranks=2)
+            synth.build_ba_graph(ba, prob)
+            ba.set_allreduce(hook)
+            ba.initialize()
+            done = [ba.optimize(n) for n in (1, 6)]
+            out[overlap] = (done, ba.get_poses()[1].copy(), ba.chi2())
+            assert len(streams) == (2 if overlap == "1" else 1), streams
+            ba.close()
+    finally:
+        if old is None:
+            os.environ.pop("SVI_LIN_OVERLAP", None)
+        else:
+            os.environ["SVI_LIN_OVERLAP"] = old
+        dist.destroy_process_group()
+    assert out["1"][0] == out["0"][0]
+    assert np.isfinite(out["1"][2][0])
+    np.testing.assert_array_equal(out["1"][1], out["0"][1])
+    assert out["1"][2] == out["0"][2]
