@@ -522,9 +522,8 @@ int svi_ba_save_g2o(svi_ba* ba, const char* path);
 /* Sum-all-reduce of `count` doubles living at device pointer `buf`, in place, ordered on
  * `stream` (a hipStream_t). Return 0 on success. The harness implements it with
  * torch.distributed / RCCL (svi_mapper_amd/dist.py); with n_ranks == 1 it is never called.
- * `stream` is either the handle's stream or a second stream the library owns (the small
- * all-reduce of the linearisation sums runs beside the Schur kernels); every rank issues its
- * calls in the same order. */
+ * Every rank issues its calls in the same order: per LM trial the reduced system and three
+ * scalars, plus the pose sums in front of the first trial of an optimize() block. */
 typedef int (*svi_allreduce_fn)(void* user, void* buf, size_t count, void* stream);
 int svi_ba_set_allreduce(svi_ba* ba, svi_allreduce_fn fn, void* user);
 

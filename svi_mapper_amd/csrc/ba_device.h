@@ -123,7 +123,11 @@ struct BaDev {
     const int* sub_tile;     // [n_sub] tile id that holds it
     const int* sub_aux_ptr;  // [n_sub+1]
     const int* sub_aux_ref;  // (se3 edge << 1) | transposed
-    int add_pose_terms;       // rank 0 adds Hpp / bp / odometry blocks
+    int add_pose_terms;       // this rank adds Hpp / bp: rank 0 when they hold the all-reduced totals, every rank when they
+                              // hold its own partial sums (summed with the reduced system then)
+    int add_aux_blocks;       // rank 0 adds the odometry off-diagonal blocks
+    int lin_from_red;         // the chi2 of the linearisation travels in front of g (red_base[0..1]) instead of in lin_buf
+    double* red_base;         // = g - 2
 
     // LM scalars on the device
     double* aux_part;  // [aux_blocks][2] chi2 partials of the pose-only edges

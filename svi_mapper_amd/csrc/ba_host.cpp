@@ -802,7 +802,8 @@ int build_structure(svi_ba* ba)
     SVI_TRY(dev_upload(ba, tile_map, &d.tile_map));
     // [ g | tiles with contributions | fill-in tiles ]: the all-reduce payload is the prefix g + contributing tiles
     d.red_count = NT * TS + n_tiles_orig * TS * TS;
-    SVI_TRY(dev_alloc(ba, (size_t)NT * TS + (size_t)n_tiles * TS * TS, &d.g));
+    SVI_TRY(dev_alloc(ba, 2 + (size_t)NT * TS + (size_t)n_tiles * TS * TS, &d.red_base)); // two doubles in front: see linearize()
+    d.g = d.red_base + 2;
     d.S = d.g + (size_t)NT * TS;
     SVI_TRY(dev_alloc(ba, (size_t)n_tiles * TS * TS, &d.Lt));
     SVI_TRY(dev_alloc(ba, (size_t)NT * TS * TS, &d.Linv));
@@ -824,7 +825,8 @@ int build_structure(svi_ba* ba)
     SVI_TRY(dev_upload(ba, sub_tile, &d.sub_tile));
     SVI_TRY(dev_upload(ba, sub_aux_ptr, &d.sub_aux_ptr));
     SVI_TRY(dev_upload(ba, sub_aux_ref, &d.sub_aux_ref));
-    d.add_pose_terms = (o.rank == 0) ? 1 : 0;
+    d.add_pose_terms = d.add_aux_blocks = (o.rank == 0) ? 1 : 0;
+    d.lin_from_red = 0;
     SVI_TRY(dev_alloc(ba, 16, &d.scal));
     d.aux_blocks = std::max(1, (std::max(d.n_se3, d.n_accel) + 63) / 64);
     SVI_TRY(dev_alloc(ba, (size_t)2 * d.aux_blocks, &d.aux_part));
@@ -954,20 +956,12 @@ int linearize(svi_ba* ba, bool read = true)
     ba_pose_finalize(d, ba->red_slot, ba->opt.rank, ba->opt.n_ranks, s);
     t.end(s);
     SVI_HIP(hipGetLastError());
-    if (ba->side && !read && ba->ar) {
-        // nobody needs the summed pose blocks before k_assemble: the collective (latency bound at this size) and the
-        // kernel behind it go to the side stream and run beside the landmark inversion and the Schur products; trial()
-        // joins the two streams in front of k_assemble
-        SVI_HIP(hipEventRecord(ba->ev_fork, s));
-        SVI_HIP(hipStreamWaitEvent(ba->side, ba->ev_fork, 0));
-        const int rc = ba->ar(ba->ar_user, d.lin_buf, (size_t)d.lin_count, ba->side);
-        if (rc != 0) return fail(SVI_ERR_COMM, "all-reduce hook returned %d", rc);
-        ba_lin_post(d, ba->opt.n_ranks, ba->side);
-        SVI_HIP(hipEventRecord(ba->ev_join, ba->side));
-        SVI_HIP(hipGetLastError());
-        ba->lin_pending = true;
-        return SVI_OK;
-    }
+    // Several ranks: the pose sums (Hpp | bp | chi2 | max diag) only have to be exchanged when the host needs
+    // max |H_jj| for lambda_0, i.e. in front of the first trial of a block.  Otherwise every rank adds its own partial
+    // Hpp / bp to its share of the reduced system and the all-reduce of that system sums them (with this rank's chi2 in
+    // the two doubles in front of g): one collective per iteration less.
+    ba->lin_local = ba->opt.n_ranks > 1 && !read && d.n_sub > 0;
+    if (ba->lin_local) return SVI_OK;
     SVI_TRY(allreduce(ba, d.lin_buf, (size_t)d.lin_count));
     ba_lin_post(d, ba->opt.n_ranks, s);
     SVI_HIP(hipGetLastError());
@@ -976,6 +970,15 @@ int linearize(svi_ba* ba, bool read = true)
 
 // one trial: solve (H + lambda I) dx = b through the Schur complement, apply, evaluate.
 // results: h_scal[0] robust chi2, [1] plain chi2, [2]+[3] step scale; *failed
+// k_assemble with the pose terms matching what linearize() left in Hpp / bp: totals (rank 0 adds them) or this rank's share
+void assemble(svi_ba* ba)
+{
+    BaDev& d = ba->d;
+    d.add_pose_terms = (ba->lin_local || ba->opt.rank == 0) ? 1 : 0;
+    d.lin_from_red = ba->lin_local ? 1 : 0;
+    ba_assemble(d, ba->stream);
+}
+
 int trial(svi_ba* ba, double lambda, bool* failed)
 {
     BaDev& d = ba->d;
@@ -986,10 +989,9 @@ int trial(svi_ba* ba, double lambda, bool* failed)
     ba_invert_landmarks(d, lambda, s);
     ba_schur(d, s);
     t.end(s);
-    if (ba->lin_pending) { SVI_HIP(hipStreamWaitEvent(s, ba->ev_join, 0)); ba->lin_pending = false; }
-    t.begin(SVI_PH_ASSEMBLE, s); ba_assemble(d, s); t.end(s);
+    t.begin(SVI_PH_ASSEMBLE, s); assemble(ba); t.end(s);
     SVI_HIP(hipGetLastError());
-    SVI_TRY(allreduce(ba, d.g, (size_t)d.red_count));
+    SVI_TRY(allreduce(ba, ba->lin_local ? d.red_base : d.g, (size_t)d.red_count + (ba->lin_local ? 2 : 0)));
     t.begin(SVI_PH_CHOLESKY, s);
     if (d.NT > 0 && chol_factor_solve(ba->plan, d.S, d.Lt, d.Linv, d.g, d.dx, lambda, 6 * d.Pf, d.chol_status, s) != 0)
         return fail(SVI_ERR_HIP, "Cholesky kernels could not be configured (LDS request refused)");
@@ -1143,13 +1145,6 @@ int svi_ba_create(const svi_ba_options* o, svi_ba** out)
         if (e != hipSuccess) { delete ba; return fail(SVI_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         ba->own_stream = true;
     }
-    const char* ov = getenv("SVI_LIN_OVERLAP"); // 0: keep every collective on the main stream (A/B switch)
-    if (o->n_ranks > 1 && !(ov && ov[0] == '0')) {
-        hipError_t e = hipStreamCreateWithFlags(&ba->side, hipStreamNonBlocking);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ba->ev_fork, hipEventDisableTiming);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&ba->ev_join, hipEventDisableTiming);
-        if (e != hipSuccess) { svi_ba_destroy(ba); return fail(SVI_ERR_HIP, "side stream: %s", hipGetErrorString(e)); }
-    }
     ba->timer.on = o->profile != 0;
     *out = ba;
     return SVI_OK;
@@ -1160,9 +1155,6 @@ int svi_ba_destroy(svi_ba* ba)
     if (!ba) return SVI_OK;
     (void)hipSetDevice(ba->opt.device);
     (void)hipStreamSynchronize(ba->stream);
-    if (ba->side) { (void)hipStreamSynchronize(ba->side); (void)hipStreamDestroy(ba->side); }
-    if (ba->ev_fork) (void)hipEventDestroy(ba->ev_fork);
-    if (ba->ev_join) (void)hipEventDestroy(ba->ev_join);
     free_device(ba);
     ba->timer.release();
     if (ba->own_stream) (void)hipStreamDestroy(ba->stream);
@@ -1626,7 +1618,7 @@ int svi_ba_debug_reduced_system(svi_ba* ba, double lambda, double* S, double* g,
     SVI_HIP(hipMemsetAsync(d.chol_status, 0, sizeof(int), ba->stream));
     ba_invert_landmarks(d, lambda, ba->stream);
     ba_schur(d, ba->stream);
-    ba_assemble(d, ba->stream);
+    assemble(ba);
     SVI_HIP(hipGetLastError());
     SVI_TRY(allreduce(ba, d.g, (size_t)d.red_count));
     const int TS = d.TS, NT = d.NT;

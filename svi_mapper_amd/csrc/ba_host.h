@@ -48,10 +48,7 @@ struct svi_ba {
     // ---- device ----
     hipStream_t stream = nullptr;
     bool own_stream = false;
-    // several ranks: the all-reduce of the linearisation sums runs on a side stream, beside the Schur kernels
-    hipStream_t side = nullptr;
-    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    bool lin_pending = false;
+    bool lin_local = false; // several ranks: the last linearisation kept its pose sums local (see linearize())
     bool initialized = false;
     svi::BaDev d{};
     svi::CholPlan plan{};

@@ -928,6 +928,9 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(BaDev d)
     __shared__ double s_part[NWA][36 * 16];
     const int sub = blockIdx.x, tid = threadIdx.x;
     const int cx = d.sub_cx[sub], cy = d.sub_cy[sub], n = 6 * d.Pf, TS = d.TS;
+    // several ranks, pose sums not exchanged on their own: this rank's chi2 of the linearisation rides in front of g
+    // (rewritten per trial: the all-reduce leaves the total there)
+    if (d.lin_from_red && sub == 0 && tid == 0) { d.red_base[0] = d.lin_scal[0]; d.red_base[1] = d.lin_scal[1]; }
     // slabs: wave w of this workgroup sums cell (u, v) = (w >> 1, w & 1) of the sub-tile.  A quarter job qj left its
     // [36][16] values at slab[(qj >> 2)][q][(qj & 3) * 16 + l16]: block (i, j) = (l16 >> 2, l16 & 3), entry (q / 6, q % 6).
     {
@@ -993,6 +996,8 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(BaDev d)
             }
         }
         __syncthreads();
+    }
+    if (d.add_aux_blocks) {
         for (int e = d.sub_aux_ptr[sub] * 36 + tid; e < d.sub_aux_ptr[sub + 1] * 36; e += kAsmThreads) {
             const int ref = d.sub_aux_ref[e / 36], k = ref >> 1, tr = ref & 1;
             const int rr = (e % 36) / 6, cc = e % 6;
@@ -1075,7 +1080,11 @@ __global__ __launch_bounds__(kRedThreads) void k_update_poses(BaDev d, int cur, 
         }
     }
     block_sum<1, NW>(part, s_red);
-    if (threadIdx.x == 0) d.scal[3] = part[0];
+    if (threadIdx.x == 0) {
+        d.scal[3] = part[0];
+        // several ranks: the chi2 of the linearisation came in with the reduced system (k_assemble put this rank's share there)
+        if (d.lin_from_red) { d.scal[8] = d.red_base[0]; d.scal[9] = d.red_base[1]; }
+    }
 }
 
 // ---------------------------------------------------------------------------------------------

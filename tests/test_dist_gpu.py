@@ -154,11 +154,11 @@ def test_rccl_hook_aliases_library_memory(svi):
         dist.destroy_process_group()
 
 
-def test_side_stream_collective_under_rccl(svi):
+def test_shard_driven_through_rccl(svi):
     """Shard 0 of 2 driven through a real RCCL communicator (1 rank: every sum is the identity, so the handle solves
-    the sub-problem of its own landmarks): the all-reduce of the linearisation sums runs on the library's side stream
-    beside the Schur kernels. With the overlap switched off (SVI_LIN_OVERLAP=0) the same kernels and collectives run
-    on one stream - the results must be bit-identical, and nothing may hang."""
+    the sub-problem of its own landmarks). Checks the collective schedule: the pose sums are exchanged on their own only
+    in front of the first trial of a block (lambda_0 needs max |H_jj|); otherwise they ride with the reduced system -
+    two collectives per trial (reduced system, three scalars), all on the handle's stream."""
     import os
     import socket
 
@@ -176,33 +176,32 @@ def test_side_stream_collective_under_rccl(svi):
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     prob = synth.make_ba_problem(40, 3000, 20000, seed=5)
     cam = prob["cam"]
-    out = {}
-    old = os.environ.get("SVI_LIN_OVERLAP")
     try:
-        for overlap in ("1", "0"):
-            os.environ["SVI_LIN_OVERLAP"] = overlap
-            streams = set()
-            inner = sdist.make_allreduce_hook()
+        calls = []
+        inner = sdist.make_allreduce_hook()
 
-            def hook(ptr, count, stream, inner=inner, streams=streams):
-                streams.add(stream)
-                return inner(ptr, count, stream)
+        def hook(ptr, count, stream):
+            calls.append((count, stream))
+            return inner(ptr, count, stream)
 
-            ba = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"], rank=0, n_ranks=2)
-            synth.build_ba_graph(ba, prob)
-            ba.set_allreduce(hook)
-            ba.initialize()
-            done = [ba.optimize(n) for n in (1, 6)]
-            out[overlap] = (done, ba.get_poses()[1].copy(), ba.chi2())
-            assert len(streams) == (2 if overlap == "1" else 1), streams
-            ba.close()
+        ba = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"], rank=0, n_ranks=2)
+        synth.build_ba_graph(ba, prob)
+        ba.set_allreduce(hook)
+        ba.initialize()
+        blocks = (1, 6)
+        done = [ba.optimize(n) for n in blocks]
+        st = ba.stats()
+        chi = ba.chi2()
+        ba.close()
     finally:
-        if old is None:
-            os.environ.pop("SVI_LIN_OVERLAP", None)
-        else:
-            os.environ["SVI_LIN_OVERLAP"] = old
         dist.destroy_process_group()
-    assert out["1"][0] == out["0"][0]
-    assert np.isfinite(out["1"][2][0])
-    np.testing.assert_array_equal(out["1"][1], out["0"][1])
-    assert out["1"][2] == out["0"][2]
+    assert done == list(blocks) and np.isfinite(chi[0])
+    assert len({stream for _, stream in calls}) == 1
+    scalars = [c for c, _ in calls if c == 3]
+    downloads = [c for c, _ in calls if c == 3 * 3000]  # the landmark gather at the end of a block (3000 landmarks)
+    big = [c for c, _ in calls if c != 3 and c != 3 * 3000]
+    assert len(downloads) == len(blocks)
+    assert len(scalars) == st.lm_trials
+    assert len(big) == st.lm_trials + len(blocks), (len(big), st.lm_trials)
+    # the reduced system carries two more doubles when the pose sums ride along
+    assert len(set(big)) == 3 and max(big) - sorted(set(big))[-2] == 2, sorted(set(big))
