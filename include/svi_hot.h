@@ -486,6 +486,12 @@ int svi_ba_optimize(svi_ba* ba, int iterations, int* performed);
  * nominal = first + block*k (the reference's counter), executed = LM iterations really run. */
 int svi_ba_optimize_until(svi_ba* ba, double ratio, int first, int block,
                           uint64_t* nominal, uint64_t* executed);
+/* The estimates stay in HBM across optimize() calls; the host copy that the getters, the write-back,
+ * the .g2o writer, graph edits and a re-initialisation read is refreshed by the first such call after an
+ * optimize() (g2o keeps its estimates in host memory: Cg2oOptimizer.cpp:1468-1540 reads them there).
+ * With n_ranks > 1 that refresh gathers the landmark shards through the all-reduce hook, so the first
+ * reading call after an optimize() must be made by every rank.  svi_ba_sync_host does it explicitly. */
+int svi_ba_sync_host(svi_ba* ba);
 /* g2o OptimizableGraph::chi2(): plain sum e' Omega e with the most recently evaluated errors;
  * robust: g2o activeRobustChi2(). Either pointer may be NULL. */
 int svi_ba_chi2(svi_ba* ba, double* plain, double* robust);

@@ -153,6 +153,7 @@ SIGNATURES = {
     "svi_ba_optimize": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
     "svi_ba_optimize_until": (C.c_int, [vp, C.c_double, C.c_int, C.c_int, u64p, u64p]),
     "svi_ba_chi2": (C.c_int, [vp, f64p, f64p]),
+    "svi_ba_sync_host": (C.c_int, [vp]),
     "svi_ba_lambda": (C.c_int, [vp, f64p]),
     "svi_ba_get_pose": (C.c_int, [vp, C.c_int64, f64p]),
     "svi_ba_get_landmark": (C.c_int, [vp, C.c_int64, f64p]),

@@ -53,6 +53,7 @@ extern "C" {
 int svi_ba_load_g2o(svi_ba* ba, const char* path)
 {
     if (!ba || !path) return fail(SVI_ERR_INVALID, "null argument");
+    if (int rc_sync = ensure_host(ba)) return rc_sync;
     std::ifstream in(path);
     if (!in) return fail(SVI_ERR_IO, "cannot open %s", path);
     std::map<int, std::array<double, 12>> offsets;
@@ -161,6 +162,7 @@ int svi_ba_load_g2o(svi_ba* ba, const char* path)
 int svi_ba_save_g2o(svi_ba* ba, const char* path)
 {
     if (!ba || !path) return fail(SVI_ERR_INVALID, "null argument");
+    if (int rc_sync = ensure_host(ba)) return rc_sync;
     FILE* f = std::fopen(path, "w");
     if (!f) return fail(SVI_ERR_IO, "cannot open %s for writing", path);
     const svi_ba_options& o = ba->opt;

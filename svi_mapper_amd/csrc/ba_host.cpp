@@ -1036,6 +1036,22 @@ int download_state(svi_ba* ba)
     return SVI_OK;
 }
 
+} // namespace
+
+// Brings the host copy of poses and landmarks in step with the device if an optimize() has run since the last read.
+// With several ranks this contains the all-gather of the landmark shards: the first reading call after an optimize()
+// is collective.
+int ensure_host(svi_ba* ba)
+{
+    if (!ba->host_stale) return SVI_OK;
+    SVI_HIP(hipSetDevice(ba->opt.device));
+    SVI_TRY(download_state(ba));
+    ba->host_stale = false;
+    return SVI_OK;
+}
+
+namespace {
+
 int optimize_block(svi_ba* ba, int iterations, int* performed)
 {
     if (!ba->initialized) return fail(SVI_ERR_STATE, "svi_ba_optimize before svi_ba_initialize");
@@ -1092,11 +1108,15 @@ int optimize_block(svi_ba* ba, int iterations, int* performed)
         if (q == o.lm_max_trials || rho == 0 || stop_inf) break; // SolverResult::Terminate
     }
     if (performed) *performed = done;
-    return download_state(ba);
+    // the estimates stay on the device; the host copy is refreshed by the first call that reads it (ensure_host)
+    ba->host_stale = true;
+    ba->timer.collect();
+    return SVI_OK;
 }
 
 int add_proj(svi_ba* ba, int type, int64_t pose_id, int64_t lm_id, const double* z, const double* info, int robust)
 {
+    SVI_TRY(ensure_host(ba));
     auto ip = ba->pose_ix.find(pose_id);
     auto il = ba->lm_ix.find(lm_id);
     if (ip == ba->pose_ix.end()) return fail(SVI_ERR_NOT_FOUND, "pose id %lld not in graph", (long long)pose_id);
@@ -1165,6 +1185,7 @@ int svi_ba_destroy(svi_ba* ba)
 int svi_ba_add_pose(svi_ba* ba, int64_t id, const double T[12], int fixed)
 {
     if (!ba || !T) return fail(SVI_ERR_INVALID, "null argument");
+    SVI_TRY(ensure_host(ba));
     if (ba->pose_ix.count(id) || ba->lm_ix.count(id)) return fail(SVI_ERR_INVALID, "vertex id %lld already in graph", (long long)id);
     HPose p{};
     p.id = id; memcpy(p.T, T, 96); p.fixed = fixed ? 1 : 0;
@@ -1177,6 +1198,7 @@ int svi_ba_add_pose(svi_ba* ba, int64_t id, const double T[12], int fixed)
 int svi_ba_add_landmark(svi_ba* ba, int64_t id, const double p[3], int fixed)
 {
     if (!ba || !p) return fail(SVI_ERR_INVALID, "null argument");
+    SVI_TRY(ensure_host(ba));
     if (ba->pose_ix.count(id) || ba->lm_ix.count(id)) return fail(SVI_ERR_INVALID, "vertex id %lld already in graph", (long long)id);
     HLm l{};
     l.id = id; memcpy(l.p, p, 24); l.fixed = fixed ? 1 : 0;
@@ -1206,6 +1228,7 @@ int svi_ba_add_edges_bulk(svi_ba* ba, int64_t n, const int32_t* type, const int6
                           const double* z, const double* info, const int32_t* robust)
 {
     if (!ba || n < 0) return fail(SVI_ERR_INVALID, "bad argument");
+    SVI_TRY(ensure_host(ba));
     if (n == 0) return SVI_OK;
     if (!type || !pose_id || !lm_id || !z || !info) return fail(SVI_ERR_INVALID, "null argument");
     const size_t before = ba->proj.size();
@@ -1220,6 +1243,7 @@ int svi_ba_add_edges_bulk(svi_ba* ba, int64_t n, const int32_t* type, const int6
 int svi_ba_add_edge_se3(svi_ba* ba, int64_t id_i, int64_t id_j, const double Z[12], const double info[21], int robust)
 {
     if (!ba || !Z || !info) return fail(SVI_ERR_INVALID, "null argument");
+    SVI_TRY(ensure_host(ba));
     auto i = ba->pose_ix.find(id_i), j = ba->pose_ix.find(id_j);
     if (i == ba->pose_ix.end() || j == ba->pose_ix.end()) return fail(SVI_ERR_NOT_FOUND, "pose id not in graph");
     if (i->second == j->second) return fail(SVI_ERR_INVALID, "EdgeSE3 between a pose and itself");
@@ -1234,6 +1258,7 @@ int svi_ba_add_edge_se3(svi_ba* ba, int64_t id_i, int64_t id_j, const double Z[1
 int svi_ba_add_edge_accel(svi_ba* ba, int64_t pose_id, const double a[3], const double off[12], const double info[6])
 {
     if (!ba || !a || !info) return fail(SVI_ERR_INVALID, "null argument");
+    SVI_TRY(ensure_host(ba));
     auto i = ba->pose_ix.find(pose_id);
     if (i == ba->pose_ix.end()) return fail(SVI_ERR_NOT_FOUND, "pose id %lld not in graph", (long long)pose_id);
     HAcc e{};
@@ -1249,6 +1274,7 @@ int svi_ba_add_edge_accel(svi_ba* ba, int64_t pose_id, const double a[3], const 
 int svi_ba_add_edge_lm_lm(svi_ba* ba, int64_t id_i, int64_t id_j, const double z[3], const double info[6], int robust)
 {
     if (!ba || !z || !info) return fail(SVI_ERR_INVALID, "null argument");
+    SVI_TRY(ensure_host(ba));
     auto i = ba->lm_ix.find(id_i), j = ba->lm_ix.find(id_j);
     if (i == ba->lm_ix.end() || j == ba->lm_ix.end()) return fail(SVI_ERR_NOT_FOUND, "landmark id not in graph");
     if (i->second == j->second) return fail(SVI_ERR_INVALID, "EdgePointXYZ between a landmark and itself");
@@ -1264,6 +1290,7 @@ int svi_ba_add_edge_lm_lm(svi_ba* ba, int64_t id_i, int64_t id_j, const double z
 int svi_ba_add_keyframe(svi_ba* ba, int64_t id, int64_t from_id, const double T[12], const double shift[3], const double accel[3])
 {
     if (!ba || !T) return fail(SVI_ERR_INVALID, "null argument");
+    SVI_TRY(ensure_host(ba));
     auto f = ba->pose_ix.find(from_id);
     if (f == ba->pose_ix.end()) return fail(SVI_ERR_NOT_FOUND, "previous keyframe id %lld not in graph", (long long)from_id);
     double X[12];
@@ -1290,6 +1317,7 @@ int svi_ba_add_measurements(svi_ba* ba, int64_t pose_id, int64_t n, const int64_
                             const double* xyz, int64_t stored[3])
 {
     if (!ba || n < 0) return fail(SVI_ERR_INVALID, "bad argument");
+    SVI_TRY(ensure_host(ba));
     if (stored) stored[0] = stored[1] = stored[2] = 0;
     if (n == 0) return SVI_OK;
     if (!lm_id || !uvL || !uvR || !xyz) return fail(SVI_ERR_INVALID, "null argument");
@@ -1335,6 +1363,7 @@ int svi_ba_add_measurements(svi_ba* ba, int64_t pose_id, int64_t n, const int64_
 int svi_ba_initialize(svi_ba* ba)
 {
     if (!ba) return fail(SVI_ERR_INVALID, "null handle");
+    SVI_TRY(ensure_host(ba));
     if (int rc = use_device(ba->opt.device)) return rc;
     free_device(ba);
     ba->cur = 0;
@@ -1388,6 +1417,12 @@ int svi_ba_chi2(svi_ba* ba, double* plain, double* robust)
     return SVI_OK;
 }
 
+int svi_ba_sync_host(svi_ba* ba)
+{
+    if (!ba) return fail(SVI_ERR_INVALID, "null handle");
+    return ensure_host(ba);
+}
+
 int svi_ba_lambda(svi_ba* ba, double* lambda)
 {
     if (!ba || !lambda) return fail(SVI_ERR_INVALID, "null argument");
@@ -1398,6 +1433,7 @@ int svi_ba_lambda(svi_ba* ba, double* lambda)
 int svi_ba_get_pose(svi_ba* ba, int64_t id, double T[12])
 {
     if (!ba || !T) return fail(SVI_ERR_INVALID, "null argument");
+    SVI_TRY(ensure_host(ba));
     auto i = ba->pose_ix.find(id);
     if (i == ba->pose_ix.end()) return fail(SVI_ERR_NOT_FOUND, "pose id %lld not in graph", (long long)id);
     memcpy(T, ba->poses[i->second].T, 96);
@@ -1407,6 +1443,7 @@ int svi_ba_get_pose(svi_ba* ba, int64_t id, double T[12])
 int svi_ba_get_landmark(svi_ba* ba, int64_t id, double p[3])
 {
     if (!ba || !p) return fail(SVI_ERR_INVALID, "null argument");
+    SVI_TRY(ensure_host(ba));
     auto i = ba->lm_ix.find(id);
     if (i == ba->lm_ix.end()) return fail(SVI_ERR_NOT_FOUND, "landmark id %lld not in graph", (long long)id);
     memcpy(p, ba->lms[i->second].p, 24);
@@ -1425,6 +1462,7 @@ int svi_ba_num_edges(svi_ba* ba, int64_t* n)
 int svi_ba_get_poses(svi_ba* ba, int64_t* ids, double* T)
 {
     if (!ba || !T) return fail(SVI_ERR_INVALID, "null argument");
+    SVI_TRY(ensure_host(ba));
     std::vector<int> ord(ba->poses.size());
     std::iota(ord.begin(), ord.end(), 0);
     std::sort(ord.begin(), ord.end(), [&](int a, int b) { return ba->poses[a].id < ba->poses[b].id; });
@@ -1435,6 +1473,7 @@ int svi_ba_get_poses(svi_ba* ba, int64_t* ids, double* T)
 int svi_ba_get_landmarks(svi_ba* ba, int64_t* ids, double* p)
 {
     if (!ba || !p) return fail(SVI_ERR_INVALID, "null argument");
+    SVI_TRY(ensure_host(ba));
     std::vector<int> ord(ba->lms.size());
     std::iota(ord.begin(), ord.end(), 0);
     std::sort(ord.begin(), ord.end(), [&](int a, int b) { return ba->lms[a].id < ba->lms[b].id; });
@@ -1446,6 +1485,7 @@ int svi_ba_get_landmarks(svi_ba* ba, int64_t* ids, double* p)
 int svi_ba_prune_diverged(svi_ba* ba, int64_t* removed)
 {
     if (!ba) return fail(SVI_ERR_INVALID, "null handle");
+    SVI_TRY(ensure_host(ba));
     const int nl = (int)ba->lms.size();
     std::vector<int> remap(nl, -1);
     int64_t gone = 0;
@@ -1479,6 +1519,7 @@ int svi_ba_apply_optimization(svi_ba* ba, const double shift[3], int64_t* lm_ids
                               double* kf_T, int64_t* erased)
 {
     if (!ba) return fail(SVI_ERR_INVALID, "null handle");
+    SVI_TRY(ensure_host(ba));
     const double s[3] = {shift ? shift[0] : 0.0, shift ? shift[1] : 0.0, shift ? shift[2] : 0.0};
     std::vector<int> ord(ba->lms.size());
     std::iota(ord.begin(), ord.end(), 0);

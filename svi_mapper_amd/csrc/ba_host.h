@@ -48,6 +48,7 @@ struct svi_ba {
     // ---- device ----
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    bool host_stale = false; // an optimize() has run since the host copy of the estimates was refreshed (ensure_host)
     bool lin_local = false; // several ranks: the last linearisation kept its pose sums local (see linearize())
     bool initialized = false;
     svi::BaDev d{};
@@ -79,3 +80,6 @@ struct svi_ba {
     void* ar_user = nullptr;
     svi::PhaseTimer timer;
 };
+
+// host copy of the estimates in step with the device (ba_host.cpp); collective with several ranks when it has to act
+int ensure_host(svi_ba* ba);

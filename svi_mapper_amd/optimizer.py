@@ -149,6 +149,10 @@ class BundleAdjuster:
         self.num_optimizations += 1
         return nom.value, exe.value
 
+    def sync_host(self):
+        """Refresh the host copy of the estimates now (the getters do it on demand; collective with several ranks)."""
+        check(self._lib.svi_ba_sync_host(self._h), "svi_ba_sync_host")
+
     def chi2(self):
         p = C.c_double(0)
         r = C.c_double(0)
