@@ -466,6 +466,10 @@ int svi_ba_add_edge_lm_lm(svi_ba* ba, int64_t id_i, int64_t id_j, const double z
  * 1e5*diag(s,s,s,1,1,1), s = 1/(1+|t_ij|^2), and the gravity edge carrying accel (NULL = 0). */
 int svi_ba_add_keyframe(svi_ba* ba, int64_t id, int64_t from_id, const double T_left_to_world[12],
                         const double shift[3], const double accel[3]);
+/* g2o::ParameterSE3Offset eOFFSET_IMUtoLEFT (Cg2oOptimizer.cpp:209-213; CPinholeCameraIMU::m_matTransformationIMUtoCAMERA of
+ * the LEFT camera): the offset every gravity edge created by svi_ba_add_keyframe carries from now on (12 doubles, R row-major
+ * then t; identity until set - the stereo-only cameras).  The edge error is R_pose R_off a - (0,0,-1). */
+int svi_ba_set_imu_offset(svi_ba* ba, const double off[12]);
 /* _setLandmarkMeasurementsWORLD (Cg2oOptimizer.cpp:1383-1466): for each measurement of a
  * landmark already in the graph apply the consistency gate 0.75 < |X^-1 l|^2/|p_m|^2 < 1.25 and
  * choose XYZ / UV-depth / UV-disparity by |p_m|^2 (10 / 50 / 10000), information from w = 1/z_m.
@@ -528,8 +532,8 @@ int svi_ba_save_g2o(svi_ba* ba, const char* path);
 /* Sum-all-reduce of `count` doubles living at device pointer `buf`, in place, ordered on
  * `stream` (a hipStream_t). Return 0 on success. The harness implements it with
  * torch.distributed / RCCL (svi_mapper_amd/dist.py); with n_ranks == 1 it is never called.
- * Every rank issues its calls in the same order: per LM trial the reduced system and three
- * scalars, plus the pose sums in front of the first trial of an optimize() block. */
+ * Every rank issues its calls in the same order: per LM trial the reduced system and four
+ * scalars (chi2 robust / plain, landmark and pose part of the step scale), plus the pose sums in front of the first trial of an optimize() block. */
 typedef int (*svi_allreduce_fn)(void* user, void* buf, size_t count, void* stream);
 int svi_ba_set_allreduce(svi_ba* ba, svi_allreduce_fn fn, void* user);
 
@@ -568,6 +572,10 @@ int svi_ba_get_stats(svi_ba* ba, svi_ba_stats* s);
 /* per projection edge, in insertion order: error (3) and Jacobians at the current estimate */
 int svi_ba_debug_edge_jacobians(svi_ba* ba, double* err /*E x 3*/, double* J_pose /*E x 18*/,
                                 double* J_lm /*E x 9*/);
+/* pose-only edges at the current estimate, in insertion order among their kind (rank 0 holds them): EdgeSE3 error (6) and
+ * its two 6x6 Jacobians (row-major, w.r.t. the increments of pose i / pose j); gravity edge error (3) and its 3x6 Jacobian */
+int svi_ba_debug_aux_jacobians(svi_ba* ba, double* se3_err /*n_se3 x 6*/, double* se3_Ji /*n_se3 x 36*/, double* se3_Jj,
+                               double* acc_err /*n_accel x 3*/, double* acc_J /*n_accel x 18*/);
 /* dense reduced system of the last linearisation with damping `lambda`:
  * S (n x n row-major, full symmetric) and g (n), n = 6 * free poses; *n_out receives n */
 int svi_ba_debug_reduced_system(svi_ba* ba, double lambda, double* S, double* g, int64_t cap,

@@ -54,6 +54,8 @@ def load(path=None):
     lib.orc_ba_destroy.argtypes = [C.c_void_p]
     lib.orc_ba_set_lm.argtypes = [C.c_void_p, C.c_double, C.c_double, C.c_double, C.c_int, C.c_double]
     lib.orc_ba_set_accel_numeric.argtypes = [C.c_void_p, C.c_int]
+    lib.orc_ba_set_imu_offset.argtypes = [C.c_void_p, _f64p]
+    lib.orc_ba_aux_jacobians.argtypes = [C.c_void_p, _f64p, _f64p, _f64p, _f64p, _f64p]
     lib.orc_ba_add_pose.argtypes = [C.c_void_p, C.c_int64, _f64p, C.c_int]
     lib.orc_ba_add_landmark.argtypes = [C.c_void_p, C.c_int64, _f64p, C.c_int]
     lib.orc_ba_add_edge_proj.argtypes = [C.c_void_p, C.c_int, C.c_int64, C.c_int64, _f64p, _f64p, C.c_int]
@@ -220,6 +222,20 @@ class OracleBA:
 
     def set_accel_numeric(self, on):
         self.lib.orc_ba_set_accel_numeric(self.h, int(on))
+
+    def set_imu_offset(self, off):
+        """IMU->LEFT offset parameter (Cg2oOptimizer.cpp:213) of the gravity edges that add_keyframe creates"""
+        off = self._d(off, 12)
+        self.lib.orc_ba_set_imu_offset(self.h, _p(off, _f64p))
+
+    def aux_jacobians(self):
+        """pose-only edges in insertion order among their kind: (se3_err n x 6, Ji n x 6 x 6, Jj, acc_err m x 3, acc_J m x 3 x 6)"""
+        t, _, _, _, _ = self.get_aux()
+        ns, na = int((t == 0).sum()), int((t == 1).sum())
+        se, si, sj = np.zeros((ns, 6)), np.zeros((ns, 6, 6)), np.zeros((ns, 6, 6))
+        ae, aj = np.zeros((na, 3)), np.zeros((na, 3, 6))
+        self.lib.orc_ba_aux_jacobians(self.h, _p(se, _f64p), _p(si, _f64p), _p(sj, _f64p), _p(ae, _f64p), _p(aj, _f64p))
+        return se, si, sj, ae, aj
 
     def add_pose(self, id, T, fixed=False):
         T = self._d(T, 12)

@@ -72,6 +72,7 @@ typedef struct {
     int    max_trials;
     double d_xyz, d_depth, d_disp, d_sane;
     int    accel_numeric; /* 1: g2o's central differences for the gravity edge (default) */
+    double imu_off[12];   /* g2o::ParameterSE3Offset eOFFSET_IMUtoLEFT (Cg2oOptimizer.cpp:209-213): R row-major, t */
 
     opose* P; int np, capp;
     olm*   L; int nl, capl;
@@ -138,6 +139,7 @@ orc_ba* orc_ba_create(double fx, double fy, double cx, double cy, double baselin
     o->tau = 1e-5; o->lo = 1.0 / 3.0; o->hi = 2.0 / 3.0; o->max_trials = 10; /* g2o LM defaults */
     o->d_xyz = 10.0; o->d_depth = 50.0; o->d_disp = 10000.0; o->d_sane = 1e12; /* Cg2oOptimizer.h:92-95 */
     o->accel_numeric = 1;
+    o->imu_off[0] = o->imu_off[4] = o->imu_off[8] = 1.0; /* stereo-only cameras: identity (:100,116) */
     omap_init(&o->mp); omap_init(&o->ml);
     return o;
 }
@@ -166,6 +168,9 @@ void orc_ba_set_lm(orc_ba* o, double tau, double lo, double hi, int max_trials, 
     o->tau = tau; o->lo = lo; o->hi = hi; o->max_trials = max_trials; o->delta = delta;
 }
 void orc_ba_set_accel_numeric(orc_ba* o, int on) { o->accel_numeric = on; }
+/* CStereoCameraIMU: m_matTransformationIMUtoCAMERA of the LEFT camera becomes the offset parameter every gravity edge
+ * refers to (Cg2oOptimizer.cpp:213, :988) */
+void orc_ba_set_imu_offset(orc_ba* o, const double off[12]) { memcpy(o->imu_off, off, 96); }
 
 int orc_ba_add_pose(orc_ba* o, int64_t id, const double T[12], int fixed)
 {
@@ -495,7 +500,7 @@ int orc_ba_add_keyframe(orc_ba* o, int64_t id, int64_t from_id, const double T[1
     info[0] = info[6] = info[11] = 100000.0 * s; info[15] = info[18] = info[20] = 100000.0; /* m_matInformationPose */
     if (orc_ba_add_edge_se3(o, from_id, id, Z, info, 0)) return 1;
     const double a0[3] = { 0, 0, 0 }, I3[6] = { 1, 0, 0, 1, 0, 1 };
-    return orc_ba_add_edge_accel(o, id, accel ? accel : a0, 0, I3);
+    return orc_ba_add_edge_accel(o, id, accel ? accel : a0, o->imu_off, I3);
 }
 
 /* Cg2oOptimizer::_setLandmarkMeasurementsWORLD (:1383-1466) with the factories (:999-1073) */
@@ -1084,6 +1089,26 @@ void orc_ba_edge_jacobians(const orc_ba* o, double* err, double* Jp, double* Jl)
         double J[27];
         proj_eval(o, e->type, o->P[e->pose].R, o->P[e->pose].t, o->L[e->lm].p, e->z, err + 3 * i, J);
         for (int r = 0; r < 3; ++r) { memcpy(Jp + 18 * i + 6 * r, J + 9 * r, 48); memcpy(Jl + 9 * i + 3 * r, J + 9 * r + 6, 24); }
+    }
+}
+/* pose-only edges in insertion order among their kind, at the current estimate: EdgeSE3 error (6) and the two 6x6
+ * Jacobians; gravity edge error (3) and its 3x6 Jacobian (numeric or analytic as orc_ba_set_accel_numeric says) */
+void orc_ba_aux_jacobians(const orc_ba* o, double* se3_err, double* se3_Ji, double* se3_Jj, double* acc_err, double* acc_J)
+{
+    int ks = 0, ka = 0;
+    for (int i = 0; i < o->na; ++i) {
+        const oaux* a = &o->A[i];
+        if (a->type == A_SE3) {
+            double Xi[12], Xj[12];
+            memcpy(Xi, o->P[a->a].R, 72); memcpy(Xi + 9, o->P[a->a].t, 24);
+            memcpy(Xj, o->P[a->b].R, 72); memcpy(Xj + 9, o->P[a->b].t, 24);
+            orc_se3_edge(Xi, Xj, a->z, se3_err + 6 * ks, se3_Ji + 36 * ks, se3_Jj + 36 * ks);
+            ++ks;
+        } else if (a->type == A_ACCEL) {
+            accel_err(o->P[a->a].R, a->off, a->z, acc_err + 3 * ka);
+            accel_jac(o, &o->P[a->a], a, acc_J + 18 * ka);
+            ++ka;
+        }
     }
 }
 /* dense H (n x n, full symmetric, row-major) and b at the current estimate; column of each vertex

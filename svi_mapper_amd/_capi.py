@@ -148,6 +148,7 @@ SIGNATURES = {
     "svi_ba_add_edge_accel": (C.c_int, [vp, C.c_int64, f64p, f64p, f64p]),
     "svi_ba_add_edge_lm_lm": (C.c_int, [vp, C.c_int64, C.c_int64, f64p, f64p, C.c_int]),
     "svi_ba_add_keyframe": (C.c_int, [vp, C.c_int64, C.c_int64, f64p, f64p, f64p]),
+    "svi_ba_set_imu_offset": (C.c_int, [vp, f64p]),
     "svi_ba_add_measurements": (C.c_int, [vp, C.c_int64, C.c_int64, i64p, f32p, f32p, f64p, i64p]),
     "svi_ba_initialize": (C.c_int, [vp]),
     "svi_ba_optimize": (C.c_int, [vp, C.c_int, C.POINTER(C.c_int)]),
@@ -171,6 +172,7 @@ SIGNATURES = {
     "svi_ba_reset_phase_times": (C.c_int, [vp]),
     "svi_ba_get_stats": (C.c_int, [vp, C.POINTER(BaStats)]),
     "svi_ba_debug_edge_jacobians": (C.c_int, [vp, f64p, f64p, f64p]),
+    "svi_ba_debug_aux_jacobians": (C.c_int, [vp, f64p, f64p, f64p, f64p, f64p]),
     "svi_ba_debug_reduced_system": (C.c_int, [vp, C.c_double, f64p, f64p, C.c_int64, i64p]),
     "svi_debug_chol_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, f64p]),
     "svi_ba_debug_time_sweep": (C.c_int, [vp, C.c_int, f64p]),

@@ -16,6 +16,7 @@
 #include <array>
 #include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <map>
 #include <sstream>
@@ -92,6 +93,7 @@ int svi_ba_load_g2o(svi_ba* ba, const char* path)
             std::array<double, 12> T;
             quat_pose(v, T.data());
             offsets[id] = T;
+            if (id == 3) memcpy(ba->imu_off, T.data(), 96); // eOFFSET_IMUtoLEFT (Cg2oOptimizer.h:26)
         } else if (tag == "PARAMS_CAMERACALIB") {
             int id; double v[11];
             is >> id;
@@ -170,10 +172,28 @@ int svi_ba_save_g2o(svi_ba* ba, const char* path)
     std::fprintf(f, "PARAMS_SE3OFFSET 0 0 0 0 0 0 0 1\n");
     std::fprintf(f, "PARAMS_CAMERACALIB 1 0 0 0 0 0 0 1 %.17g %.17g %.17g %.17g\n", o.fx, o.fy, o.cx, o.cy);
     std::fprintf(f, "PARAMS_CAMERACALIB 2 0 0 0 0 0 0 1 %.17g %.17g %.17g %.17g\n", o.fx, o.fy, o.cx, o.cy);
-    // one IMU offset parameter per distinct offset would need ids; the reference has exactly one (id 3)
-    double off7[7] = {0, 0, 0, 0, 0, 0, 1};
-    if (!ba->acc.empty()) pose_quat(ba->acc[0].off, off7);
+    // offset parameters: id 0 is the identity ("world"), id 3 the handle's IMU->LEFT offset (the only ones the reference has);
+    // a gravity edge added with an offset of its own (svi_ba_add_edge_accel) gets a further parameter, ids 4, 5, ...
+    std::vector<std::array<double, 12>> offs;
+    std::vector<int> off_id, acc_pid(ba->acc.size(), 3);
+    auto same = [](const double* a, const double* b) { for (int k = 0; k < 12; ++k) if (a[k] != b[k]) return false; return true; };
+    static const double kIdent[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
+    for (size_t k = 0; k < ba->acc.size(); ++k) {
+        const double* o12 = ba->acc[k].off;
+        if (same(o12, ba->imu_off)) continue;
+        if (same(o12, kIdent)) { acc_pid[k] = 0; continue; }
+        size_t q = 0;
+        while (q < offs.size() && !same(o12, offs[q].data())) ++q;
+        if (q == offs.size()) { std::array<double, 12> t; memcpy(t.data(), o12, 96); offs.push_back(t); off_id.push_back(4 + (int)q); }
+        acc_pid[k] = off_id[q];
+    }
+    double off7[7];
+    pose_quat(ba->imu_off, off7);
     std::fprintf(f, "PARAMS_SE3OFFSET 3 %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", off7[0], off7[1], off7[2], off7[3], off7[4], off7[5], off7[6]);
+    for (size_t q = 0; q < offs.size(); ++q) {
+        pose_quat(offs[q].data(), off7);
+        std::fprintf(f, "PARAMS_SE3OFFSET %d %.17g %.17g %.17g %.17g %.17g %.17g %.17g\n", off_id[q], off7[0], off7[1], off7[2], off7[3], off7[4], off7[5], off7[6]);
+    }
     std::vector<int64_t> fixed;
     for (const HLm& l : ba->lms) {
         std::fprintf(f, "VERTEX_TRACKXYZ %lld %.17g %.17g %.17g\n", (long long)l.id, l.p[0], l.p[1], l.p[2]);
@@ -186,8 +206,9 @@ int svi_ba_save_g2o(svi_ba* ba, const char* path)
         if (p.fixed) fixed.push_back(p.id);
     }
     for (int64_t id : fixed) std::fprintf(f, "FIX %lld\n", (long long)id);
-    for (const HAcc& e : ba->acc) {
-        std::fprintf(f, "EDGE_SE3_LINEAR_ACCELERATION %lld 3 %.17g %.17g %.17g", (long long)ba->poses[e.pose].id, e.a[0], e.a[1], e.a[2]);
+    for (size_t k = 0; k < ba->acc.size(); ++k) {
+        const HAcc& e = ba->acc[k];
+        std::fprintf(f, "EDGE_SE3_LINEAR_ACCELERATION %lld %d %.17g %.17g %.17g", (long long)ba->poses[e.pose].id, acc_pid[k], e.a[0], e.a[1], e.a[2]);
         for (double x : e.info) std::fprintf(f, " %.17g", x);
         std::fprintf(f, "\n");
     }

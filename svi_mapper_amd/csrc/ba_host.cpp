@@ -36,11 +36,12 @@ void ba_lin_post(const BaDev& d, int n_ranks, void* st);
 void ba_invert_landmarks(const BaDev& d, double lambda, void* st);
 void ba_schur(const BaDev& d, void* st);
 void ba_assemble(const BaDev& d, void* st);
-void ba_update_poses(const BaDev& d, int cur, double lambda, void* st);
+void ba_update_poses(const BaDev& d, int cur, double lambda, int scale_mode, int rank, void* st);
 void ba_backsub_chi2(const BaDev& d, int cur, double lambda, void* st);
 void ba_chi2_only(const BaDev& d, int which, void* st);
 void ba_reduce_trial_scalars(const BaDev& d, int n_pub, double* h_scal, int* h_status, int seq, void* st);
 void ba_debug_jacobians(const BaDev& d, int cur, const int* e_orig, double* err, double* Jp, double* Jl, void* st);
+void ba_debug_aux_jacobians(const BaDev& d, int cur, double* se3_err, double* se3_Ji, double* se3_Jj, double* acc_err, double* acc_J, void* st);
 void ba_configure_kernels(int TS);
 int chol_potrf_probe(int tile, int reps, int stop_after, double* ms);
 int chol_factor_solve(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n,
@@ -939,7 +940,7 @@ int reduce_and_read_trial(svi_ba* ba, int n)
     }
     ba_reduce_trial_scalars(ba->d, 0, nullptr, nullptr, 0, ba->stream);
     SVI_HIP(hipGetLastError());
-    SVI_TRY(allreduce(ba, ba->d.scal, 3));
+    SVI_TRY(allreduce(ba, ba->d.scal, 4)); // chi2 robust / plain, landmark and pose parts of the step scale
     return read_scalars(ba, n);
 }
 
@@ -997,7 +998,7 @@ int trial(svi_ba* ba, double lambda, bool* failed)
         return fail(SVI_ERR_HIP, "Cholesky kernels could not be configured (LDS request refused)");
     t.end(s);
     t.begin(SVI_PH_BACKSUB_UPDATE, s);
-    ba_update_poses(d, ba->cur, lambda, s);
+    ba_update_poses(d, ba->cur, lambda, ba->opt.n_ranks <= 1 ? 0 : (ba->lin_local ? 2 : 1), ba->opt.rank, s);
     ba_backsub_chi2(d, ba->cur, lambda, s);
     t.end(s);
     t.begin(SVI_PH_CHI2, s);
@@ -1309,7 +1310,15 @@ int svi_ba_add_keyframe(svi_ba* ba, int64_t id, int64_t from_id, const double T[
     info[15] = info[18] = info[20] = 100000.0;
     SVI_TRY(svi_ba_add_edge_se3(ba, from_id, id, Z, info, 0));
     const double a0[3] = {0, 0, 0}, I3[6] = {1, 0, 0, 1, 0, 1};
-    return svi_ba_add_edge_accel(ba, id, accel ? accel : a0, nullptr, I3);
+    return svi_ba_add_edge_accel(ba, id, accel ? accel : a0, ba->imu_off, I3);
+}
+
+// the offset parameter every gravity edge of svi_ba_add_keyframe refers to (Cg2oOptimizer.cpp:213, :988)
+int svi_ba_set_imu_offset(svi_ba* ba, const double off[12])
+{
+    if (!ba || !off) return fail(SVI_ERR_INVALID, "null argument");
+    memcpy(ba->imu_off, off, 96);
+    return SVI_OK;
 }
 
 // Cg2oOptimizer::_setLandmarkMeasurementsWORLD (:1383-1466) with the factories (:999-1073)
@@ -1595,6 +1604,30 @@ int svi_ba_debug_edge_jacobians(svi_ba* ba, double* err, double* J_pose, double*
     (void)hipFree(de);
     if (e1 != hipSuccess || e2 != hipSuccess || e3 != hipSuccess || e4 != hipSuccess || e5 != hipSuccess)
         return fail(SVI_ERR_HIP, "debug_edge_jacobians: HIP failure");
+    return SVI_OK;
+}
+
+int svi_ba_debug_aux_jacobians(svi_ba* ba, double* se3_err, double* se3_Ji, double* se3_Jj, double* acc_err, double* acc_J)
+{
+    if (!ba || !se3_err || !se3_Ji || !se3_Jj || !acc_err || !acc_J) return fail(SVI_ERR_INVALID, "null argument");
+    if (!ba->initialized) return fail(SVI_ERR_STATE, "debug tap before svi_ba_initialize");
+    if (ba->opt.rank != 0) return fail(SVI_ERR_STATE, "pose-only edges live on rank 0");
+    SVI_HIP(hipSetDevice(ba->opt.device));
+    const size_t ns = ba->se3.size(), na = ba->acc.size(), total = 78 * ns + 21 * na;
+    double* dev = nullptr;
+    SVI_HIP(hipMalloc(reinterpret_cast<void**>(&dev), sizeof(double) * std::max<size_t>(total, 1)));
+    double *d_se = dev, *d_si = d_se + 6 * ns, *d_sj = d_si + 36 * ns, *d_ae = d_sj + 36 * ns, *d_aj = d_ae + 3 * na;
+    ba_debug_aux_jacobians(ba->d, ba->cur, d_se, d_si, d_sj, d_ae, d_aj, ba->stream);
+    std::vector<double> h(std::max<size_t>(total, 1));
+    hipError_t e1 = hipMemcpyAsync(h.data(), dev, sizeof(double) * total, hipMemcpyDeviceToHost, ba->stream);
+    hipError_t e2 = hipStreamSynchronize(ba->stream);
+    (void)hipFree(dev);
+    if (e1 != hipSuccess || e2 != hipSuccess) return fail(SVI_ERR_HIP, "debug_aux_jacobians: HIP failure");
+    memcpy(se3_err, h.data(), sizeof(double) * 6 * ns);
+    memcpy(se3_Ji, h.data() + 6 * ns, sizeof(double) * 36 * ns);
+    memcpy(se3_Jj, h.data() + 42 * ns, sizeof(double) * 36 * ns);
+    memcpy(acc_err, h.data() + 78 * ns, sizeof(double) * 3 * na);
+    memcpy(acc_J, h.data() + 78 * ns + 3 * na, sizeof(double) * 18 * na);
     return SVI_OK;
 }
 

@@ -44,6 +44,8 @@ struct svi_ba {
     std::vector<svi::HAcc>  acc;
     std::vector<svi::HLL>   lmlm;
     std::unordered_map<int64_t, int> pose_ix, lm_ix;
+    // g2o::ParameterSE3Offset eOFFSET_IMUtoLEFT (Cg2oOptimizer.cpp:209-213): the offset of the gravity edges of add_keyframe
+    double imu_off[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
 
     // ---- device ----
     hipStream_t stream = nullptr;

@@ -503,6 +503,22 @@ __global__ __launch_bounds__(kBlock) void k_linearize_pose(BaDev d, int cur)
 // pose-only edges (odometry EdgeSE3, gravity EdgeSE3LinearAcceleration): a single workgroup,
 // LINEARIZE: also the quadratic forms.  Writes aux chi2 (robust, plain) to d.scal[6], d.scal[7].
 // ---------------------------------------------------------------------------------------------
+// EdgeSE3LinearAcceleration: e = R (R_off a) - (0,0,-1) with v = R_off a folded on the host (edge_se3_linear_acceleration.cpp:
+// 106-116; the cache's n2w() is the pose times the offset parameter).  J (3x6, nullable): d e / d dt = 0, d e / d dq = -2 R [v]x
+// - analytic where g2o differentiates numerically (BaseUnaryEdge::linearizeOplus, central differences with 1e-9).
+__device__ __forceinline__ void accel_edge_eval(const double* R, const double* v, double* e, double* J)
+{
+    e[0] = R[0] * v[0] + R[1] * v[1] + R[2] * v[2];
+    e[1] = R[3] * v[0] + R[4] * v[1] + R[5] * v[2];
+    e[2] = R[6] * v[0] + R[7] * v[1] + R[8] * v[2] + 1.0;
+    if (!J) return;
+    const double S[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
+    for (int r = 0; r < 3; ++r) {
+        J[6 * r] = J[6 * r + 1] = J[6 * r + 2] = 0.0;
+        for (int c = 0; c < 3; ++c) J[6 * r + 3 + c] = -2.0 * (R[3 * r] * S[c] + R[3 * r + 1] * S[3 + c] + R[3 * r + 2] * S[6 + c]);
+    }
+}
+
 constexpr int kAuxThreads = 64; // one edge per lane, one wavefront per workgroup: the edges spread over many CUs
 
 template <bool LINEARIZE>
@@ -555,25 +571,16 @@ __global__ __launch_bounds__(kAuxThreads) void k_aux_edges(BaDev d, int which)
         }
     }
     for (int k = gid; k < d.n_accel; k += gridDim.x * kAuxThreads) {
-        const int s = d.acc_pose[k];
-        const double* R = pose + 12 * s;
+        const double* R = pose + 12 * d.acc_pose[k];
         const double v[3] = {d.acc_a[3 * k], d.acc_a[3 * k + 1], d.acc_a[3 * k + 2]};
-        // e = R v - (0,0,-1)   (edge_se3_linear_acceleration.cpp:106-116)
-        const double e[3] = {R[0] * v[0] + R[1] * v[1] + R[2] * v[2], R[3] * v[0] + R[4] * v[1] + R[5] * v[2],
-                             R[6] * v[0] + R[7] * v[1] + R[8] * v[2] + 1.0};
+        double e[3], J[18];
+        accel_edge_eval(R, v, e, LINEARIZE ? J : nullptr);
         double O[6];
         for (int q = 0; q < 6; ++q) O[q] = d.acc_info[6 * k + q];
         const double c2 = e[0] * (O[0] * e[0] + 2.0 * (O[1] * e[1] + O[2] * e[2])) + e[1] * (O[3] * e[1] + 2.0 * O[4] * e[2]) +
                           e[2] * O[5] * e[2];
         part[0] += c2; part[1] += c2;
         if (LINEARIZE) {
-            // d e / d dq = -2 R [v]x ; d e / d dt = 0
-            const double S[9] = {0, -v[2], v[1], v[2], 0, -v[0], -v[1], v[0], 0};
-            double J[18];
-            for (int r = 0; r < 3; ++r) {
-                J[6 * r] = J[6 * r + 1] = J[6 * r + 2] = 0.0;
-                for (int c = 0; c < 3; ++c) J[6 * r + 3 + c] = -2.0 * (R[3 * r] * S[c] + R[3 * r + 1] * S[3 + c] + R[3 * r + 2] * S[6 + c]);
-            }
             const double Of[9] = {O[0], O[1], O[2], O[1], O[3], O[4], O[2], O[4], O[5]};
             double* out = d.acc_out + (size_t)42 * k;
             for (int r = 0; r < 6; ++r) {
@@ -1060,7 +1067,10 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(BaDev d)
 // ---------------------------------------------------------------------------------------------
 // K7 (poses): trial pose = pose [+] dx (g2o VertexSE3::oplusImpl); pose part of g2o's computeScale.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kRedThreads) void k_update_poses(BaDev d, int cur, double lambda)
+// Several ranks (scale_mode): the sum below must come out as ONE global number after the all-reduce of the trial scalars.
+//   0  one rank: everything                       1  bp holds the exchanged totals: rank 0 reports the sum, the others 0
+//   2  bp holds this rank's partial sums (linearisation kept local): every rank reports dx.bp_rank, rank 0 adds lambda |dx|^2
+__global__ __launch_bounds__(kRedThreads) void k_update_poses(BaDev d, int cur, double lambda, int scale_mode, int rank)
 {
     // one workgroup (the step scale is a single sum), but wide: with 1024 threads a trajectory of up to 1024 poses is one
     // pass of "index, then operands" round trips instead of several
@@ -1075,7 +1085,8 @@ __global__ __launch_bounds__(kRedThreads) void k_update_poses(BaDev d, int cur, 
             for (int k = 0; k < 12; ++k) dst[12 * s + k] = src[12 * s + k];
         } else {
             double dl[6];
-            for (int k = 0; k < 6; ++k) { dl[k] = d.dx[6 * r + k]; part[0] += dl[k] * (lambda * dl[k] + d.bp[6 * r + k]); }
+            const double wl = (scale_mode == 0 || rank == 0) ? lambda : 0.0, wb = (scale_mode == 1 && rank != 0) ? 0.0 : 1.0;
+            for (int k = 0; k < 6; ++k) { dl[k] = d.dx[6 * r + k]; part[0] += dl[k] * (wl * dl[k] + wb * d.bp[6 * r + k]); }
             pose_oplus(src + 12 * s, dl, dst + 12 * s);
         }
     }
@@ -1265,6 +1276,27 @@ __global__ __launch_bounds__(kBlock) void k_debug_jacobians(BaDev d, int cur, co
     }
 }
 
+// parity tap: errors and Jacobians of the pose-only edges through the same device functions as k_aux_edges
+__global__ __launch_bounds__(kAuxThreads) void k_debug_aux_jacobians(BaDev d, int cur, double* se3_err, double* se3_Ji, double* se3_Jj,
+                                                                     double* acc_err, double* acc_J)
+{
+    const double* __restrict__ pose = d.pose[cur];
+    const int gid = blockIdx.x * kAuxThreads + threadIdx.x;
+    for (int k = gid; k < d.n_se3; k += gridDim.x * kAuxThreads) {
+        double e[6], Ji[36], Jj[36];
+        se3_edge_eval(pose + 12 * d.se3_i[k], pose + 12 * d.se3_j[k], d.se3_Z + 12 * k, e, Ji, Jj);
+        for (int q = 0; q < 6; ++q) se3_err[6 * k + q] = e[q];
+        for (int q = 0; q < 36; ++q) { se3_Ji[36 * k + q] = Ji[q]; se3_Jj[36 * k + q] = Jj[q]; }
+    }
+    for (int k = gid; k < d.n_accel; k += gridDim.x * kAuxThreads) {
+        const double v[3] = {d.acc_a[3 * k], d.acc_a[3 * k + 1], d.acc_a[3 * k + 2]};
+        double e[3], J[18];
+        accel_edge_eval(pose + 12 * d.acc_pose[k], v, e, J);
+        for (int q = 0; q < 3; ++q) acc_err[3 * k + q] = e[q];
+        for (int q = 0; q < 18; ++q) acc_J[18 * k + q] = J[q];
+    }
+}
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------------
@@ -1326,9 +1358,9 @@ void ba_assemble(const BaDev& d, void* st)
 {
     if (d.n_sub > 0) hipLaunchKernelGGL(k_assemble, dim3(d.n_sub), dim3(kAsmThreads), 0, S_(st), d);
 }
-void ba_update_poses(const BaDev& d, int cur, double lambda, void* st)
+void ba_update_poses(const BaDev& d, int cur, double lambda, int scale_mode, int rank, void* st)
 {
-    hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(kRedThreads), 0, S_(st), d, cur, lambda);
+    hipLaunchKernelGGL(k_update_poses, dim3(1), dim3(kRedThreads), 0, S_(st), d, cur, lambda, scale_mode, rank);
 }
 void ba_backsub_chi2(const BaDev& d, int cur, double lambda, void* st)
 {
@@ -1349,6 +1381,11 @@ void ba_reduce_trial_scalars(const BaDev& d, int n_pub, double* h_scal, int* h_s
 void ba_debug_jacobians(const BaDev& d, int cur, const int* e_orig, double* err, double* Jp, double* Jl, void* st)
 {
     if (d.E > 0) hipLaunchKernelGGL(k_debug_jacobians, dim3((d.E + kBlock - 1) / kBlock), dim3(kBlock), 0, S_(st), d, cur, e_orig, err, Jp, Jl);
+}
+
+void ba_debug_aux_jacobians(const BaDev& d, int cur, double* se3_err, double* se3_Ji, double* se3_Jj, double* acc_err, double* acc_J, void* st)
+{
+    hipLaunchKernelGGL(k_debug_aux_jacobians, dim3(d.aux_blocks), dim3(kAuxThreads), 0, S_(st), d, cur, se3_err, se3_Ji, se3_Jj, acc_err, acc_J);
 }
 
 void ba_configure_kernels(int) {}

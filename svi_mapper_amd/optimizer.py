@@ -104,6 +104,11 @@ class BundleAdjuster:
         check(self._lib.svi_ba_add_edge_lm_lm(self._h, int(i), int(j), _p(z, f64p), _p(info, f64p), int(robust)),
               "svi_ba_add_edge_lm_lm")
 
+    def set_imu_offset(self, off):
+        """IMU->LEFT offset parameter (Cg2oOptimizer.cpp:213) of the gravity edges that add_keyframe creates"""
+        off = _d(off, 12)
+        check(self._lib.svi_ba_set_imu_offset(self._h, _p(off, f64p)), "svi_ba_set_imu_offset")
+
     def add_keyframe(self, id, from_id, T, shift=None, accel=None):
         T = _d(T, 12)
         shift = _d(shift, 3) if shift is not None else None
@@ -275,6 +280,16 @@ class BundleAdjuster:
         check(self._lib.svi_ba_debug_edge_jacobians(self._h, _p(e, f64p), _p(Jp, f64p), _p(Jl, f64p)),
               "svi_ba_debug_edge_jacobians")
         return e, Jp, Jl
+
+    def aux_jacobians(self):
+        """pose-only edges in insertion order among their kind: (se3_err n x 6, Ji n x 6 x 6, Jj, acc_err m x 3, acc_J m x 3 x 6)"""
+        st = self.stats()
+        ns, na = st.n_edges_se3, st.n_edges_accel
+        se, si, sj = np.zeros((ns, 6)), np.zeros((ns, 6, 6)), np.zeros((ns, 6, 6))
+        ae, aj = np.zeros((na, 3)), np.zeros((na, 3, 6))
+        check(self._lib.svi_ba_debug_aux_jacobians(self._h, _p(se, f64p), _p(si, f64p), _p(sj, f64p), _p(ae, f64p), _p(aj, f64p)),
+              "svi_ba_debug_aux_jacobians")
+        return se, si, sj, ae, aj
 
     def reduced_system(self, lam):
         n = 6 * self.stats().n_poses_free

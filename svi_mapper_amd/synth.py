@@ -121,18 +121,21 @@ def trajectory(n_kf, step=1.0, straight=40, turn=15):
 
 
 def make_ba_problem(n_kf=100, n_lm=20000, n_edges=150000, seed=0xC3, px_sigma=0.5,
-                    pose_sigma_t=0.05, pose_sigma_r_deg=0.5, max_run=40, pose_init=None):
+                    pose_sigma_t=0.05, pose_sigma_r_deg=0.5, max_run=40, pose_init=None, cam=None, traj=None,
+                    depth_range=(2.5, 90.0), max_depth=95.0):
     """Raw synthetic problem (numpy). Keys:
       cam, R_true,t_true, R_init,t_init (LEFT->WORLD), lm_true, lm_init,
-      obs_kf, obs_lm (sorted by keyframe), uvL, uvR (float32), xyz (f64, getPointInLEFT of the pixels)"""
+      obs_kf, obs_lm (sorted by keyframe), uvL, uvR (float32), xyz (f64, getPointInLEFT of the pixels)
+    cam / traj / depth_range / max_depth default to the KITTI-00 shape of configs 3 and 4."""
     rng = np.random.default_rng(seed)
-    cam = kitti_camera()
+    cam = kitti_camera() if cam is None else cam
     f, cx, cy, dur = cam["fx"], cam["cx"], cam["cy"], cam["duR_flipped"]
-    R, t = trajectory(n_kf)
+    KITTI_WIDTH, KITTI_HEIGHT = cam["width"], cam["height"]  # (the names of the default camera: shadowed on purpose)
+    R, t = trajectory(n_kf) if traj is None else traj
 
     # landmark birth keyframe: uniform, leaving room for >= 2 observations
     k0 = np.sort(rng.integers(0, max(1, n_kf - 1), n_lm))
-    z = np.exp(rng.uniform(np.log(2.5), np.log(90.0), n_lm))
+    z = np.exp(rng.uniform(np.log(depth_range[0]), np.log(depth_range[1]), n_lm))
     u = rng.uniform(FOV_BORDER, KITTI_WIDTH - FOV_BORDER, n_lm)
     v = rng.uniform(FOV_BORDER, KITTI_HEIGHT - FOV_BORDER, n_lm)
     pc = np.stack([z * (u - cx) / f, z * (v - cy) / f, z], 1)
@@ -147,7 +150,7 @@ def make_ba_problem(n_kf=100, n_lm=20000, n_edges=150000, seed=0xC3, px_sigma=0.
         zc = np.maximum(p[:, 2], 1e-9)
         uu = f * p[:, 0] / zc + cx
         vv = f * p[:, 1] / zc + cy
-        return inb & (p[:, 2] > 1.0) & (p[:, 2] < 95.0) & (uu >= FOV_BORDER) & (uu < KITTI_WIDTH - FOV_BORDER) & \
+        return inb & (p[:, 2] > min(1.0, 0.5 * depth_range[0])) & (p[:, 2] < max_depth) & (uu >= FOV_BORDER) & (uu < KITTI_WIDTH - FOV_BORDER) & \
             (vv >= FOV_BORDER) & (vv < KITTI_HEIGHT - FOV_BORDER)
 
     fwd = np.zeros(n_lm, np.int64)
@@ -248,6 +251,87 @@ def make_ba_problem(n_kf=100, n_lm=20000, n_edges=150000, seed=0xC3, px_sigma=0.
                 uvL=uvL[order], uvR=uvR[order], xyz=xyz[order])
 
 
+# ------------------------------------------------------------------------------------------------
+# C5: vi_sensor stereo + IMU (hardware_parameters/vi_sensor_camera_left.txt, ..._right.txt in the reference)
+# ------------------------------------------------------------------------------------------------
+VI_WIDTH = 752
+VI_HEIGHT = 480
+VI_F = 450.5097158071153          # matProjection(0,0) of both rectified cameras (vi_sensor_camera_left.txt:19)
+VI_CX = 375.9431800842285
+VI_CY = 222.3379611968994
+VI_DUR_FLIPPED = 49.63250853439215  # -P_R(0,3)  (vi_sensor_camera_right.txt:19)
+# vecQuaternionToIMU (x, y, z, w), vecTranslationToIMU, matRotationIntrinsicCAMERAtoIMU (vi_sensor_camera_*.txt:15-16, 21)
+VI_Q_LEFT = (-0.00333631563313, 0.00154028789643, -0.0114620263178, 0.999927556608)
+VI_T_LEFT = (0.0666914200614, 0.0038316133947, -0.0101029245794)
+VI_Q_RIGHT = (-0.00186686047363, 6.55239757426e-05, -0.00862255915657, 0.999961080249)
+VI_T_RIGHT = (-0.0434705406089, 0.00417949317011, -0.00942355850866)
+VI_R_CORRECTION = np.diag([-1.0, -1.0, 1.0])
+
+
+def _quat_R(x, y, z, w):
+    n = np.sqrt(x * x + y * y + z * z + w * w)
+    x, y, z, w = x / n, y / n, z / n, w / n
+    return np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)],
+                     [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+
+
+def _vi_camera_to_imu(q, t):
+    """CPinholeCameraIMU (CPinholeCameraIMU.h:36-50): R_CAMERAtoIMU = correction * R(q), translation as given"""
+    return VI_R_CORRECTION @ _quat_R(*q), np.asarray(t, np.float64)
+
+
+def vi_sensor_imu_to_left():
+    """m_matTransformationIMUtoCAMERA of the LEFT camera as 12 doubles (R row-major, t): the g2o offset parameter
+    eOFFSET_IMUtoLEFT (Cg2oOptimizer.cpp:213)"""
+    Rc, tc = _vi_camera_to_imu(VI_Q_LEFT, VI_T_LEFT)
+    return np.concatenate([Rc.T.reshape(9), -Rc.T @ tc])
+
+
+def vi_sensor_camera():
+    """CStereoCameraIMU (CStereoCameraIMU.h:21-25): the baseline is |translation of RIGHTtoIMU^-1 * LEFTtoIMU|"""
+    Rl, tl = _vi_camera_to_imu(VI_Q_LEFT, VI_T_LEFT)
+    Rr, tr = _vi_camera_to_imu(VI_Q_RIGHT, VI_T_RIGHT)
+    base = float(np.linalg.norm(Rr.T @ (tl - tr)))
+    return dict(fx=VI_F, fy=VI_F, cx=VI_CX, cy=VI_CY, baseline_m=base, duR_flipped=VI_DUR_FLIPPED, width=VI_WIDTH,
+                height=VI_HEIGHT)
+
+
+def vi_trajectory(n_kf, seed=0, step=0.72):
+    """hand-held walk: a key frame every sqrt(0.5) m or so (CTrackerSVI.h:53), slow turns plus a little roll and pitch -
+    the attitude changes are what the gravity edges see"""
+    r = np.random.default_rng(seed)
+    k = np.arange(n_kf)
+    heading = 0.6 * np.sin(2 * np.pi * k / 37.0) + 0.02 * k
+    R = _rot_y(heading) @ _small_rot(np.stack([0.05 * np.sin(k / 5.0), np.zeros(n_kf), 0.04 * np.cos(k / 7.0)], 1))
+    fwd = R[:, :, 2]
+    t = np.zeros((n_kf, 3))
+    t[1:] = np.cumsum(fwd[:-1] * step, axis=0)
+    t[:, 1] += 0.03 * np.sin(k / 3.0)
+    del r
+    return R, t
+
+
+def make_vi_problem(n_kf=60, n_lm=6000, n_edges=40000, seed=0xC5, accel_sigma=0.01, **kw):
+    """BASELINE config 5 as a BA graph: the vi_sensor camera, indoor depths, and per key frame the NORMALISED accelerometer
+    reading (CTrackerSVI.cpp:651) in the IMU frame: a = (R_k R_off)' g + noise, g = (0,0,-1) - whatever direction that is
+    in the camera frame of the first key frame, the edges only ask for consistency with the poses.  Extra keys: accel
+    (n_kf x 3, unit norm), imu_off (12), accel_first = (0,-1,0) of the constructor's edge (Cg2oOptimizer.cpp:154)."""
+    cam = vi_sensor_camera()
+    R, t = vi_trajectory(n_kf, seed)
+    prob = make_ba_problem(n_kf, n_lm, n_edges, seed, cam=cam, traj=(R, t), depth_range=(0.8, 25.0), max_depth=30.0,
+                           pose_sigma_t=kw.pop("pose_sigma_t", 0.03), **kw)
+    off = vi_sensor_imu_to_left()
+    R_off = off[:9].reshape(3, 3)
+    rng = np.random.default_rng(seed + 17)
+    g = np.array([0.0, 0.0, -1.0])
+    a = np.einsum("ij,nkj,k->ni", R_off.T, R, g)      # R_off' R_k' g
+    a = a + rng.normal(0, accel_sigma, a.shape)
+    a /= np.linalg.norm(a, axis=1, keepdims=True)
+    prob.update(accel=a, imu_off=off, accel_first=np.array([0.0, -1.0, 0.0]))
+    return prob
+
+
 def make_c3(seed=0xC3):
     return make_ba_problem(100, 20000, 150000, seed)
 
@@ -295,14 +379,18 @@ def build_ba_graph(ba, prob):
     Returns the per-kind edge counts [xyz, depth, disparity]."""
     n_kf = prob["n_kf"]
     ids_lm = np.arange(prob["n_lm"], dtype=np.int64)
+    imu = prob.get("imu_off")       # config 5: the IMU constructor's first edge and offset (Cg2oOptimizer.cpp:154, :213)
+    if imu is not None:
+        ba.set_imu_offset(imu)
     ba.add_pose(POSE_ID_SHIFT, pose12(prob["R_init"][0], prob["t_init"][0]), fixed=True)
-    ba.add_edge_accel(POSE_ID_SHIFT, np.zeros(3))
+    ba.add_edge_accel(POSE_ID_SHIFT, prob.get("accel_first", np.zeros(3)), imu)
     ba.add_landmarks(ids_lm, prob["lm_init"])
     starts = np.searchsorted(prob["obs_kf"], np.arange(n_kf + 1))
     stored = np.zeros(3, np.int64)
     for k in range(n_kf):
         if k > 0:
-            ba.add_keyframe(POSE_ID_SHIFT + k, POSE_ID_SHIFT + k - 1, pose12(prob["R_init"][k], prob["t_init"][k]))
+            ba.add_keyframe(POSE_ID_SHIFT + k, POSE_ID_SHIFT + k - 1, pose12(prob["R_init"][k], prob["t_init"][k]),
+                            accel=prob["accel"][k] if "accel" in prob else None)
         a, b = starts[k], starts[k + 1]
         if b > a:
             stored += ba.add_measurements(POSE_ID_SHIFT + k, prob["obs_lm"][a:b].astype(np.int64),

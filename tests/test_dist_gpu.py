@@ -10,10 +10,11 @@ from svi_mapper_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _run_sharded(svi, prob, n_ranks, iters, extra=None):
-    """n_ranks handles in n_ranks threads of one process; the hook sums their buffers in a fixed order."""
+def _run_sharded(svi, prob, n_ranks, iters, extra=None, make=None):
+    """n_ranks handles in n_ranks threads of one process; the hook sums their buffers in a fixed order.
+    make(rank, n_ranks) (optional) builds the handle with its graph instead of synth.build_ba_graph(prob)."""
     import torch
-    cam = prob["cam"]
+    cam = prob["cam"] if prob is not None else None
     barrier = threading.Barrier(n_ranks)
     slots = [None] * n_ranks
     out = [None] * n_ranks
@@ -40,15 +41,22 @@ def _run_sharded(svi, prob, n_ranks, iters, extra=None):
 
     def work(rank):
         try:
-            ba = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"], rank=rank, n_ranks=n_ranks)
-            synth.build_ba_graph(ba, prob)
+            if make is not None:
+                ba = make(rank, n_ranks)
+            else:
+                ba = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"], rank=rank, n_ranks=n_ranks)
+                synth.build_ba_graph(ba, prob)
             if extra is not None:
                 extra(ba)
             ba.set_allreduce(hook_for(rank))
             ba.initialize()
-            done = [ba.optimize(n) for n in iters]
+            done, lams = [], []
+            for n in iters:
+                done.append(ba.optimize(n))
+                lams.append(ba.lm_lambda)
             st = ba.stats()
-            out[rank] = (done, ba.get_poses()[1], ba.get_landmarks()[1], ba.chi2(), st.n_landmarks_local, st.lm_trials, st.chol_failures)
+            out[rank] = (done, ba.get_poses()[1], ba.get_landmarks()[1], ba.chi2(), st.n_landmarks_local, st.lm_trials, st.chol_failures,
+                         lams)
             ba.close()
         except Exception as e:  # noqa: BLE001
             errs.append(e)
@@ -111,6 +119,37 @@ def test_failed_trial_is_failed_on_every_rank(svi):
         assert np.abs(o[1] - ref.get_poses()[1]).max() < 1e-8
 
 
+@pytest.mark.parametrize("rot,seed", [(0.3, 3), (0.35, 6), (0.35, 8)])
+def test_rejected_trials_identical_on_every_rank(svi, rot, seed):
+    """Overshooting Gauss-Newton steps (the graphs of test_ba_gpu.test_rejected_trials_follow_g2o): 0 < rho < 1 and rejected
+    trials, so lambda depends on the step scale sum dx (lambda dx + b).  In the iterations whose linearisation stays local
+    every rank holds only its partial b_p: the pose part of the scale must still come out as one global sum, or the ranks
+    damp differently and drift apart (round-1 advisor finding)."""
+    from test_ba_gpu import _nonlinear_graph
+    iters = (1, 3, 3)
+    ref = _nonlinear_graph(svi.BundleAdjuster, 1e-12, rot, seed=seed)
+    ref.initialize()
+    done, lams = [], []
+    for n in iters:
+        done.append(ref.optimize(n))
+        lams.append(ref.lm_lambda)
+    st = ref.stats()
+    assert st.lm_trials > st.lm_iterations, "the graph was supposed to provoke rejected trials"
+
+    def make(rank, n_ranks):
+        import functools
+        cls = functools.partial(svi.BundleAdjuster, rank=rank, n_ranks=n_ranks)
+        return _nonlinear_graph(cls, 1e-12, rot, seed=seed)
+
+    out = _run_sharded(svi, None, 2, iters, make=make)
+    for o in out:
+        assert o[0] == done and o[5] == st.lm_trials
+        assert np.allclose(o[7], lams, rtol=1e-4, atol=0)       # the same damping history as one rank ...
+        assert o[7] == out[0][7]                                # ... and bit-identical between the ranks
+        assert np.array_equal(o[1], out[0][1])
+        assert np.abs(o[1] - ref.get_poses()[1]).max() <= 1e-4 * np.abs(ref.get_poses()[1]).max()
+
+
 def test_missing_hook_fails_loudly(svi):
     prob = synth.make_ba_problem(6, 60, 330, seed=42)
     cam = prob["cam"]
@@ -158,7 +197,7 @@ def test_shard_driven_through_rccl(svi):
     """Shard 0 of 2 driven through a real RCCL communicator (1 rank: every sum is the identity, so the handle solves
     the sub-problem of its own landmarks). Checks the collective schedule: the pose sums are exchanged on their own only
     in front of the first trial of a block (lambda_0 needs max |H_jj|); otherwise they ride with the reduced system -
-    two collectives per trial (reduced system, three scalars), all on the handle's stream."""
+    two collectives per trial (reduced system, four scalars), all on the handle's stream."""
     import os
     import socket
 
@@ -201,9 +240,9 @@ def test_shard_driven_through_rccl(svi):
         dist.destroy_process_group()
     assert done == list(blocks) and np.isfinite(chi[0])
     assert len({stream for _, stream in calls}) == 1
-    scalars = [c for c, _ in calls if c == 3]
+    scalars = [c for c, _ in calls if c == 4]
     downloads = [c for c, _ in calls if c == 3 * 3000]  # the gather of the landmark shards (3000 landmarks)
-    big = [c for c, _ in calls if c != 3 and c != 3 * 3000]
+    big = [c for c, _ in calls if c != 4 and c != 3 * 3000]
     assert len(downloads) == 1  # lazily, by the first call that reads the estimates (none between the blocks)
     assert len(scalars) == st.lm_trials
     assert len(big) == st.lm_trials + len(blocks), (len(big), st.lm_trials)
