@@ -55,16 +55,45 @@ def cached_problem(scale):
     return prob
 
 
+LM_BLOCK = 10   # Cg2oOptimizer::_optimizeUnLimited runs optimize(10) blocks (Cg2oOptimizer.cpp:975)
+
+
 def run_exact(ba, n):
-    """exactly n LM iterations (a block that terminates early is followed by a fresh block, like the
-    reference's while loop would)"""
+    """exactly n LM iterations in the reference's blocks of 10 (lambda re-initialised per block, Appendix B); a block
+    that terminates early is followed by a fresh block, like the reference's while loop would"""
     done = 0
     while done < n:
-        r = ba.optimize(n - done)
+        r = ba.optimize(min(LM_BLOCK, n - done))
         if r <= 0:
             raise RuntimeError("optimize performed no iteration")
         done += r
     return done
+
+
+def bench_optimize_call(svi, prob, device, label):
+    """What one Cg2oOptimizer::optimize costs behind the boundary once the graph is in the handle (Cg2oOptimizer.cpp:
+    503-510): initializeOptimization (structure analysis + upload), _optimizeUnLimited, write-back incl. the read-back of
+    the estimates.  Wall-clock on the host."""
+    import torch
+    from svi_mapper_amd import synth
+    cam = prob["cam"]
+    ba = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"], device=device)
+    synth.build_ba_graph(ba, prob)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    ba.initialize()
+    t1 = time.perf_counter()
+    nominal, executed = ba.optimize_until()
+    t2 = time.perf_counter()
+    ba.apply_optimization()
+    t3 = time.perf_counter()
+    # the second call on the same (unchanged) handle: what re-initialising costs when the structures are warm
+    ba.initialize()
+    t4 = time.perf_counter()
+    ba.close()
+    return {"workload": label, "initialize_ms": 1e3 * (t1 - t0), "optimize_until_ms": 1e3 * (t2 - t1), "write_back_ms": 1e3 * (t3 - t2),
+            "total_ms": 1e3 * (t3 - t0), "iterations_nominal": int(nominal), "iterations_executed": int(executed),
+            "reinitialize_ms": 1e3 * (t4 - t3)}
 
 
 def bench_config3(svi, device, steps=20, warmup=5):
@@ -88,6 +117,7 @@ def bench_config3(svi, device, steps=20, warmup=5):
            "value": steps / dt, "unit": "iterations/s", "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
            "chol_levels": int(st.chol_steps), "reduced_tiles": int(st.chol_tiles_nnz), "stored_edges": [int(x) for x in stored]}
     ba.close()
+    out["optimize_call"] = bench_optimize_call(svi, prob, device, "config 3")
     return out
 
 
@@ -123,29 +153,44 @@ def bench_matcher(svi, steps=1000, warmup=50):
         ms = e0.elapsed_time(e1) / n
         return ms, float(batch) * nq * nt / (ms * 1e-3)
 
+    # desc-pairs/s = NQ * NT / kernel time of one call with the gate evaluated per pair as a predicate
+    m.set_gate_path(1)
     ms, rate = timed(1, True, steps, warmup)
-    # pairs that actually pass the epipolar gate (same row, u window): the candidates the reference would have enumerated
+    out["gated_predicate_single"] = {"ms_per_call": ms, "pairs_per_s": rate}
+    ms, rate = timed(64, True, max(steps // 10, 20), 5)
+    out["gated_predicate_batch64"] = {"ms_per_call": ms, "pairs_per_s": rate}
+    m.set_gate_path(0)
+    # the default path of a gated call: the pool bucketed by image row, a query visits only its candidates - far fewer
+    # pairs are looked at, so this is reported per call and per candidate, NOT as NQ * NT / t
     g = c2["gate"]
     tv, tu = g["t_uv"][:, 1], g["t_uv"][:, 0]
     cand = 0
     for i in range(nq):
         cand += int(((np.abs(tv - g["q_uv"][i, 1]) <= g.get("v_tol", 0.0)) & (tu >= g["q_umin"][i]) & (tu < g["q_umax"][i])).sum())
-    out["gated_single"] = {"ms_per_call": ms, "pairs_per_s": rate, "gated_candidates": cand, "gated_candidates_per_s": cand / (ms * 1e-3)}
-    ms, rate = timed(64, True, max(steps // 10, 20), 5)
-    out["gated_batch64"] = {"ms_per_call": ms, "pairs_per_s": rate}
+    ms, _ = timed(1, True, steps, warmup)
+    out["gated_rowbucket_single"] = {"ms_per_call": ms, "gated_candidates": cand, "gated_candidates_per_s": cand / (ms * 1e-3)}
+    ms, _ = timed(64, True, max(steps // 10, 20), 5)
+    out["gated_rowbucket_batch64"] = {"ms_per_call": ms, "gated_candidates_per_s": 64 * cand / (ms * 1e-3)}
     ms, rate = timed(1, False, steps, warmup)
     out["ungated_single"] = {"ms_per_call": ms, "pairs_per_s": rate}
     ms, rate = timed(64, False, max(steps // 10, 20), 5)
     out["ungated_batch64"] = {"ms_per_call": ms, "pairs_per_s": rate}
-    # 180 224 algorithmic bytes per call, 17 integer lane-ops per pair
+    # 180 224 algorithmic bytes per call, 17 integer lane-ops per pair; the binding resource is integer VALU
+    # issue: n_cu x 64 lane-ops per cycle at the clock measured while the chip does exactly this kind of work
     alg_bytes = 32 * (nq + nt) + 8 * (nq + nt) + 8 * nq
+    mhz = m.shader_clock_mhz()
+    n_cu = torch.cuda.get_device_properties(dev).multi_processor_count
+    peak = n_cu * 64 * mhz * 1e6
     b = out["ungated_batch64"]
-    out["roofline"] = {"bound": "valu-int", "algorithmic_bytes_per_pair_set": alg_bytes,
-                       "hbm_GBps_batch64": 64 * alg_bytes / (b["ms_per_call"] * 1e-3) / 1e9,
-                       "lane_ops_per_s_batch64": 17.0 * b["pairs_per_s"]}
+    out["roofline"] = {"bound": "valu-int", "unit": "lane-ops/s", "achieved": 17.0 * b["pairs_per_s"], "peak": peak,
+                       "frac": 17.0 * b["pairs_per_s"] / peak if peak > 0 else None, "kernel": "k_match_hamming256 (ungated, batch of 64 pair sets)",
+                       "lane_ops_per_pair": 17, "shader_clock_mhz_measured": mhz, "compute_units": n_cu,
+                       "frac_single_call_predicate": 17.0 * out["gated_predicate_single"]["pairs_per_s"] / peak if peak > 0 else None,
+                       "algorithmic_bytes_per_pair_set": alg_bytes,
+                       "hbm_GBps_batch64": 64 * alg_bytes / (b["ms_per_call"] * 1e-3) / 1e9}
     m.close()
-    return {"metric": "stereo desc-pairs/sec", "workload": "config 2: 2x2048 BRIEF-256, epipolar-gated, KITTI-00 camera",
-            "value": out["gated_single"]["pairs_per_s"], "unit": "pairs/s", "dtype": "u8", **out}
+    return {"metric": "stereo desc-pairs/sec", "workload": "config 2: 2x2048 BRIEF-256, epipolar gate evaluated per pair, KITTI-00 camera, one call",
+            "value": out["gated_predicate_single"]["pairs_per_s"], "unit": "pairs/s", "dtype": "u8", **out}
 
 
 def bench_frontend(svi, reps=200):
@@ -260,9 +305,14 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = N x config 4 landmarks over the same key frames (headline), strong = the literal config 4 "
+                         "split N ways; the other one is measured too and reported beside the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matcher", action="store_true")
     ap.add_argument("--no-frontend", action="store_true")
+    ap.add_argument("--no-replay", action="store_true", help="skip the back-to-back sweep replays (rocprof runs: the kernel stats "
+                    "then hold in-loop launches only)")
     ap.add_argument("--cpu-iters", type=int, default=30)
     ap.add_argument("--chol-tile", type=int, default=96)
     ap.add_argument("--backend", default="nccl")
@@ -281,61 +331,100 @@ def main():
     local = local % max(torch.cuda.device_count(), 1)   # more ranks than GPUs only happens in the gloo rehearsal on one card
     torch.cuda.set_device(local)
     if world > 1:
-        # rank 0 generates (and caches) the synthetic graph, the others pick the cache up afterwards
+        # rank 0 generates (and caches) the synthetic graphs, the others pick the cache up afterwards
         if rank == 0:
             cached_problem(world)
+            cached_problem(1)
         dist.barrier()
-    prob = cached_problem(world)
-    cam = prob["cam"]
-
-    def make(profile):
-        ba = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"], device=local, rank=rank,
-                                n_ranks=world, profile=profile, chol_tile=args.chol_tile)
-        stored = synth.build_ba_graph(ba, prob)
-        if world > 1:
-            ba.set_allreduce(sdist.make_allreduce_hook())
-        ba.initialize()
-        return ba, stored
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    # ---- timed run -------------------------------------------------------------------------------
-    ba, stored = make(False)
-    run_exact(ba, args.warmup)
-    s0 = ba.stats()
-    barrier()
-    t0 = time.perf_counter()
-    run_exact(ba, args.steps)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.backend == "gloo" else "cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
-    s1 = ba.stats()
-    trials = (s1.lm_trials - s0.lm_trials) / max(1, s1.lm_iterations - s0.lm_iterations)
-    chi_plain, chi_robust = ba.chi2()
-    # the metric is quoted with the state resident on the device; what one read-back of the optimised
-    # poses and landmarks to the host costs (with several ranks: incl. the gather of the shards) is reported beside it
-    t1 = time.perf_counter()
-    ba.sync_host()
-    readback_ms = 1e3 * (time.perf_counter() - t1)
-    ba.close()
+    def measure(prob, steps, warmup):
+        """one handle per rank over `prob` (landmark-sharded `world` ways), W untimed + K timed LM iterations"""
+        cam = prob["cam"]
+        ba = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"], device=local, rank=rank, n_ranks=world,
+                                chol_tile=args.chol_tile)
+        stored = synth.build_ba_graph(ba, prob)
+        if world > 1:
+            ba.set_allreduce(sdist.make_allreduce_hook())
+        ba.initialize()
+        run_exact(ba, warmup)
+        s0 = ba.stats()
+        barrier()
+        t0 = time.perf_counter()
+        run_exact(ba, steps)
+        barrier()
+        dt = time.perf_counter() - t0
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device="cpu" if args.backend == "gloo" else "cuda")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        s1 = ba.stats()
+        trials = (s1.lm_trials - s0.lm_trials) / max(1, s1.lm_iterations - s0.lm_iterations)
+        chi = ba.chi2()
+        # the metric is quoted with the state resident on the device (SURVEY 8d-i); what one read-back of the optimised
+        # poses and landmarks to the host costs (with several ranks: incl. the gather of the shards) is reported beside it
+        t1 = time.perf_counter()
+        ba.sync_host()
+        readback_ms = 1e3 * (time.perf_counter() - t1)
+        ba.close()
+        return dict(dt=dt, stats=s1, trials=trials, chi=chi, readback_ms=readback_ms, stored=stored)
 
-    # ---- profiled run: per-phase device time from HIP events on the library's stream -----------------
-    bap, _ = make(True)
+    # ---- timed run -------------------------------------------------------------------------------
+    scale_of = {"weak": world, "strong": 1}
+    prob = cached_problem(scale_of[args.scaling])
+    cam = prob["cam"]
+    head = measure(prob, args.steps, args.warmup)
+    dt, stored = head["dt"], head["stored"]
+    units = world if args.scaling == "weak" else 1     # weak: shard-iterations per second over the whole job
+    other = None
+    if world > 1:
+        mode = "strong" if args.scaling == "weak" else "weak"
+        o = measure(cached_problem(scale_of[mode]), args.steps, args.warmup)
+        ou = world if mode == "weak" else 1
+        other = {"scaling": mode, "value": ou * args.steps / o["dt"], "unit": "iterations/s", "ms_per_step": 1e3 * o["dt"] / args.steps,
+                 "landmarks_total": int(o["stats"].n_landmarks), "edges_total": int(o["stats"].n_edges_proj),
+                 "landmarks_per_gpu": int(o["stats"].n_landmarks_local), "allreduce_doubles_per_trial": int(o["stats"].reduce_doubles),
+                 "note": "strong = the literal config 4 (500 key frames / 100 k landmarks / 800 k edges) split %d ways, value = iterations/s of "
+                         "that one graph; weak = %d x config-4 landmarks over the same key frames, value = %d x iterations/s" % (world, world, world)}
+
+    def make(**kw):
+        ba = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"], device=local, rank=rank,
+                                n_ranks=world, chol_tile=args.chol_tile, **kw)
+        synth.build_ba_graph(ba, prob)
+        if world > 1:
+            ba.set_allreduce(sdist.make_allreduce_hook())
+        ba.initialize()
+        return ba
+
+    # ---- the Jacobian sweep where it runs: HIP event pairs around K2 + K3 of every linearisation inside the ordinary LM loop
+    # (no other instrumentation, the host waits on the published trial scalars only; between two sweeps the Schur, Cholesky
+    # and back-substitution kernels of the trials run and push the sweep's operands around the cache hierarchy) -----------
+    bae = make(sweep_events=True)
+    run_exact(bae, args.warmup)
+    bae.reset_phase_times()
+    run_exact(bae, args.steps)
+    loop_ms, loop_n = bae.sweep_time()
+    sweep_loop_ms = loop_ms / max(loop_n, 1)
+    bae.close()
+
+    # ---- profiled run: per-phase device time from HIP events on the library's stream (every phase synchronised) ------
+    bap = make(profile=True)
     run_exact(bap, args.warmup)
     bap.reset_phase_times()
     run_exact(bap, args.steps)
     phases = bap.phase_times()
     st = bap.stats()
-    bap.time_sweep(1000)             # warm-up, untimed: ~45 ms of back-to-back sweeps so that the clocks have ramped up after the
-                                     # (mostly idle, fully synchronised) profiled run above
-    sweep_ms = bap.time_sweep(200)  # HIP events around 200 back-to-back sweeps (K2 then K3) on the library's stream
-    sweep_parts = (bap.time_sweep(200, 1), bap.time_sweep(200, 2))
+    sweep_replay_ms = sweep_cold_ms = None
+    sweep_parts = (None, None)
+    if not args.no_replay:
+        bap.time_sweep(1000)                    # untimed: clocks ramped up after the mostly idle profiled run
+        sweep_replay_ms = bap.time_sweep(200)   # 200 back-to-back sweeps: operands warm in the 256 MiB Infinity Cache
+        sweep_parts = (bap.time_sweep(200, 1), bap.time_sweep(200, 2))
+        sweep_cold_ms = bap.time_sweep_cold(20, 640 << 20)   # every sweep behind a 640 MiB fill: nothing of it cached
     bap.close()
 
     if rank != 0:
@@ -344,7 +433,8 @@ def main():
         return
     E, P, L = int(st.n_edges_proj_local), int(st.n_poses), int(st.n_landmarks_local)
     sweep_bytes = 328 * E + 96 * P + 24 * L
-    achieved = sweep_bytes / (sweep_ms * 1e-3) / 1e9 if sweep_ms > 0 else 0.0
+    gbs = lambda ms: sweep_bytes / (ms * 1e-3) / 1e9 if ms else None  # noqa: E731
+    achieved = gbs(sweep_loop_ms) or 0.0
     ms_chol, n_chol = phases["cholesky"]
     chol_ms = ms_chol / max(n_chol, 1)
     pmc = None
@@ -352,28 +442,43 @@ def main():
         pmc = json.load(open(os.path.join(ROOT, "profiles", "pmc_traffic.json"))).get("sweep_hbm_bytes_per_launch")
     except Exception:
         pass
+    hs = head["stats"]
     line = {
-        "metric": "LM-BA iterations/sec", "value": world * args.steps / dt, "unit": "iterations/s", "n_gpus": world,
+        "metric": "LM-BA iterations/sec", "value": units * args.steps / dt, "unit": "iterations/s", "n_gpus": world,
         "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * dt / args.steps, "higher_is_better": True,
-        "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+        "scaling": args.scaling, "vs_baseline": None, "dtype": "f64", "data": "synthetic",
         "config": {"workload": "config 4: KITTI-00-shaped BA, 500 keyframes x %d landmarks x %d projection edges "
                                "(xyz %d / uv-depth %d / uv-disparity %d) + 499 odometry + 500 gravity edges; "
-                               "%d-way landmark-sharded, reference LM schedule" % (int(st.n_landmarks), int(st.n_edges_proj), stored[0], stored[1], stored[2], world),
-                   "keyframes": P, "landmarks_per_gpu": L, "edges_per_gpu": E, "parallelism": "landmark-shard x%d" % world,
-                   "chol_tile": int(st.chol_tile), "reduced_n": int(st.chol_n), "reduced_tiles": int(st.chol_tiles_nnz),
-                   "trials_per_iteration": trials, "final_chi2_plain": chi_plain, "final_chi2_robust": chi_robust,
-                   "allreduce_doubles_per_trial": int(st.reduce_doubles) if world > 1 else 0,
-                   "state": "resident in HBM during the timed iterations (SURVEY 8d-i)", "readback_ms_once": readback_ms},
-        "roofline": {"bound": "hbm", "kernel": "Jacobian sweep = k_linearize_lm (K2) + k_linearize_pose (K3), timed back to back", "achieved": achieved,
-                     "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS, "traffic": pmc,
-                     "algorithmic_bytes": sweep_bytes, "avg_ms": sweep_ms,
-                     "avg_ms_k2_alone": sweep_parts[0], "avg_ms_k3_alone": sweep_parts[1]},
+                               "%d-way landmark-sharded, reference LM schedule (blocks of %d iterations)"
+                               % (int(hs.n_landmarks), int(hs.n_edges_proj), stored[0], stored[1], stored[2], world, LM_BLOCK),
+                   "keyframes": P, "landmarks_per_gpu": int(hs.n_landmarks_local), "edges_per_gpu": int(hs.n_edges_proj_local),
+                   "parallelism": "landmark-shard x%d" % world,
+                   "chol_tile": int(hs.chol_tile), "reduced_n": int(hs.chol_n), "reduced_tiles": int(hs.chol_tiles_nnz),
+                   "trials_per_iteration": head["trials"], "final_chi2_plain": head["chi"][0], "final_chi2_robust": head["chi"][1],
+                   "allreduce_doubles_per_trial": int(hs.reduce_doubles) if world > 1 else 0,
+                   "state": "resident in HBM during the timed iterations (SURVEY 8d-i)", "readback_ms_once": head["readback_ms"]},
+        "roofline": {"bound": "hbm", "kernel": "Jacobian sweep = k_linearize_lm (K2) + k_linearize_pose (K3)",
+                     "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                     "measured": "HIP event pairs around K2+K3 of all %d linearisations inside the non-synchronised LM loop" % loop_n,
+                     "algorithmic_bytes": sweep_bytes, "avg_ms": sweep_loop_ms,
+                     "frac_replay": (gbs(sweep_replay_ms) or 0.0) / HBM_PEAK_GBS if sweep_replay_ms else None, "avg_ms_replay": sweep_replay_ms,
+                     "frac_cold": (gbs(sweep_cold_ms) or 0.0) / HBM_PEAK_GBS if sweep_cold_ms else None, "avg_ms_cold": sweep_cold_ms,
+                     "frac_profiled_loop": (gbs((phases["linearize_lm"][0] + phases["linearize_pose"][0]) / max(phases["linearize_lm"][1], 1)) or 0.0) / HBM_PEAK_GBS,
+                     "avg_ms_k2_alone_replay": sweep_parts[0], "avg_ms_k3_alone_replay": sweep_parts[1],
+                     "traffic": pmc,
+                     "traffic_note": "bytes at the L2 <-> fabric boundary (FETCH_SIZE + WRITE_SIZE, corrected per MI355X_MICROARCH.md), "
+                                     "Infinity-Cache hits included, from the committed rocprofv3 --pmc passes of this workload "
+                                     "(profiles/pmc_traffic.json) - a constant of the profile, not measured in this run"},
         "roofline_cholesky": {"bound": "mfma", "kernel": "tile-sparse LL' (potrf+trsm+gemm+solve)", "achieved": st.chol_flops / (chol_ms * 1e-3) / 1e12 if chol_ms > 0 else 0.0,
                               "peak": FP64_MFMA_PEAK_TF, "unit": "TFLOP/s", "flops": st.chol_flops, "avg_ms": chol_ms},
         "phases_ms_per_call": {k: (v[0] / v[1] if v[1] else 0.0) for k, v in phases.items()},
         "phases_calls": {k: v[1] for k, v in phases.items()},
     }
     line["roofline_cholesky"]["frac"] = line["roofline_cholesky"]["achieved"] / FP64_MFMA_PEAK_TF
+    if other is not None:
+        line["other_scaling"] = other
+    if world == 1:
+        line["optimize_call"] = bench_optimize_call(svi, prob, local, "config 4")
     if world == 1 and not args.no_matcher:
         line["config3"] = bench_config3(svi, local)
         line["matcher"] = bench_matcher(svi)

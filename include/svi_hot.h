@@ -81,6 +81,15 @@ int svi_matcher_sync(svi_matcher* m);
 /* the hipStream_t the handle launches on */
 void* svi_matcher_stream(svi_matcher* m);
 
+/* How a gated call on a small pool runs: 0 (default) the pool is bucketed by image row in LDS and a query visits only the
+ * rows its window touches; 1 the gate is evaluated as a predicate on every (query, pool) pair inside the brute-force scan
+ * (what SURVEY.md 8d-ii quotes pairs/s on).  Results are identical. */
+int svi_matcher_set_gate_path(svi_matcher* m, int path);
+
+/* measured shader clock (MHz) while all CUs run integer VALU work: the denominator of the matcher's lane-op roofline
+ * (n_cu x 64 lane-ops per cycle) */
+int svi_debug_shader_clock_mhz(svi_matcher* m, double* mhz);
+
 /* k=1 brute force Hamming NN over 256-bit descriptors (32 B rows, contiguous).
  *   out_idx[i]  = smallest j attaining min_j popcount(q_i ^ t_j) over gated j,
  *                 or -1 if there is no candidate or min >= max_dist_exclusive
@@ -305,6 +314,93 @@ int svi_brief_compute_dev(svi_brief* b, int side, const int32_t* roi, const int3
                           int64_t total_in, int32_t* seg_out, float* kp_out, uint8_t* desc_out, int64_t* total_out);
 
 /* ------------------------------------------------------------------------------------------
+ * The cascades themselves - CFundamentalMatcher's entry points (src/core/CFundamentalMatcher.h:112-170) behind the
+ * boundary: the C++ host composes the passes above (masks instead of the reference's exceptions, its own HIP kernels
+ * for the glue; the host waits only where a ragged pool has to be sized).  One svi_tracker per camera pair, bound to a
+ * matcher (stream, device).  BRIEF extraction is either the built-in svi_brief or the caller's extractor; GFTT
+ * detection (stage 2) is the caller's detector.
+ * ---------------------------------------------------------------------------------------- */
+typedef struct svi_tracker svi_tracker;
+
+/* cv::DescriptorExtractor::compute( image( roi ), keypoints, descriptors ) for n regions of image `side` (0 LEFT,
+ * 1 RIGHT) at once.  Device pointers, work ordered on `stream` (the matcher's hipStream_t; the callback may
+ * synchronise it).  roi n x 4 f32 (x, y, w, h as handed to cv::Rect), seg n+1 i32, kp_uv total_in x 2 f32 in ROI
+ * coordinates; total_in = rows behind kp_uv and room in the outputs (an upper bound: seg[n] is the number of key points).
+ * Outputs: the key points kept (OpenCV drops those near the ROI border) per region in input order, their 32-byte
+ * descriptors, seg_out n+1, *total_out = rows kept.  Return 0 on success. */
+typedef int (*svi_extract_fn)(void* user, int side, const float* roi, const int32_t* seg, const float* kp_uv, int n,
+                              int64_t total_in, int32_t* seg_out, float* kp_out, uint8_t* desc_out, int64_t* total_out,
+                              void* stream);
+/* cv::FeatureDetector::detect( image( rect ), keypoints ) for n search rectangles (rect n x 4 f32: upper-left and
+ * lower-right corner, as CFundamentalMatcher.cpp:505-509 builds cv::Rect from them); rows with active[i] == 0 must get
+ * an empty segment.  kp_out (room for `cap` rows) in rectangle coordinates, seg_out n+1, *total_out <= cap. */
+typedef int (*svi_detect_fn)(void* user, int side, const float* rect, const uint8_t* active, int n, int64_t cap,
+                             int32_t* seg_out, float* kp_out, int64_t* total_out, void* stream);
+
+int svi_tracker_create(svi_matcher* m, const svi_track_camera* cam, svi_tracker** out);
+int svi_tracker_destroy(svi_tracker* t);
+/* the built-in BRIEF extractor (svi_brief_set_image_dev must have been called for the frame) ... */
+int svi_tracker_set_brief(svi_tracker* t, svi_brief* b);
+/* ... or the caller's (replaces the built-in one; fn == NULL removes it) */
+int svi_tracker_set_extractor(svi_tracker* t, svi_extract_fn fn, void* user);
+/* key points the detector may return per call (`capacity` rows of kp_out are provided) */
+int svi_tracker_set_detector(svi_tracker* t, svi_detect_fn fn, void* user, int64_t capacity);
+
+/* the active landmarks of a frame, SoA device arrays of n rows (CLandmark: vecPointXYZOptimized, dKeyPointSize,
+ * getLastDisparity(), vecUVReferenceLEFT, the detection point it belongs to, getLastDescriptorLEFT / RIGHT,
+ * matDescriptorReferenceLEFT).  The arrays must stay valid until the cascades of the frame have run. */
+typedef struct svi_track_landmarks {
+    int            n;
+    const double*  xyz_world;       /* n x 3 */
+    const float*   kp_size;         /* n     */
+    const float*   last_disparity;  /* n     */
+    const double*  uv_reference;    /* n x 2 */
+    const int32_t* dp_index;        /* n     */
+    const uint8_t* last_desc_left;  /* n x 32, 16-byte aligned */
+    const uint8_t* last_desc_right; /* n x 32 */
+    const uint8_t* ref_desc_left;   /* n x 32 (stage 3 only) */
+} svi_track_landmarks;
+
+/* outcome per landmark (device arrays of n rows, caller-owned): status SVI_TRK_MATCH_* (SKIPPED where no stage ran),
+ * stage (nullable) 1 / 2 / 3 = the stage that produced the measurement, 0 none; the measurement (CMatchTracking /
+ * CSolverStereoPosit::CMatch: ptUVLEFT, ptUVRIGHT, vecPointXYZLEFT) and the descriptors found are valid where
+ * status == SVI_TRK_MATCH_OK */
+typedef struct svi_track_result {
+    int32_t* status;
+    int8_t*  stage;
+    float*   uv_left;    /* n x 2 */
+    float*   uv_right;   /* n x 2 */
+    double*  xyz_left;   /* n x 3 */
+    uint8_t* desc_left;  /* n x 32 */
+    uint8_t* desc_right; /* n x 32 */
+} svi_track_result;
+
+/* svi_track_plan_dev for the frame, kept inside the tracker (host transforms as there) */
+int svi_tracker_plan(svi_tracker* t, const double* T_world_to_left, const double* dp_T_left_to_world, int n_dp,
+                     double motion_scaling, const svi_track_landmarks* lm);
+/* (re)binds the descriptor arrays of the frame's landmarks (n x 32 each, 16-byte aligned) without planning again */
+int svi_tracker_set_descriptors(svi_tracker* t, const uint8_t* last_desc_left, const uint8_t* last_desc_right,
+                                const uint8_t* ref_desc_left);
+/* the plan of the frame: device records (n) and stage-3 segment table (n+1), total samples */
+int svi_tracker_records(svi_tracker* t, const svi_track_record** records, const int32_t** s3_seg, int64_t* total_samples);
+
+/* active: u8 per landmark, nullable (= all).  Every call below initialises *out first (SKIPPED / 0). */
+/* stage 1 of getPoseStereoPosit / trackManual (:391-486): descriptor at the projection, LEFT then RIGHT, stereo partner */
+int svi_track_stage1(svi_tracker* t, const uint8_t* active, const svi_track_result* out);
+/* stage 2 (:489-709): detector inside the search rectangle, LEFT then RIGHT */
+int svi_track_stage2(svi_tracker* t, const uint8_t* active, const svi_track_result* out);
+/* trackEpipolar (:794-1315): landmarks whose detection point has moved are searched along the clipped epipolar line
+ * (recursion depths 0 and 2, _getMatch, _addMeasurementToLandmarkLEFT); the others by stage 2 (:1026-1290) */
+int svi_track_epipolar(svi_tracker* t, const uint8_t* active, const svi_track_result* out);
+/* trackManual (:1366-2019): stage 1 -> stage 2 -> epipolar, each for what the previous one lost */
+int svi_track_manual(svi_tracker* t, const uint8_t* active, const svi_track_result* out);
+/* addNewLandmarks (:83-193): stereo partner + triangulation of n freshly detected LEFT key points
+ * (getPointTriangulatedInRIGHTFull: search window fMinimumSearchRangePixels = 60, no depth gate, no second descriptor
+ * check); needs no plan.  out->stage is not written. */
+int svi_track_add_new_landmarks(svi_tracker* t, const float* uv_left, const float* kp_size, const uint8_t* desc_left,
+                                int n, const svi_track_result* out);
+
+/* ------------------------------------------------------------------------------------------
  * Frame pose from the stage-1/2 matches — replaces CSolverStereoPosit::getTransformationWORLDtoLEFT
  * (src/optimization/CSolverStereoPosit.cpp:8-170): iteratively re-weighted Gauss-Newton on the
  * stereo reprojection error, the whole loop in ONE launch (no host round trip per iteration).
@@ -347,6 +443,13 @@ int svi_stereo_posit_dev(svi_matcher* m, const svi_posit_params* prm, const doub
                          const double* t_imu, const double* T_world_to_left_estimate, const double* xyz_world,
                          const float* uv_left, const float* uv_right, const uint8_t* active, int n,
                          svi_posit_result* result);
+
+/* getPoseStereoPosit (:340-760): stage 1 -> stage 2 over the landmarks with active != 0 (bIsOptimal), then
+ * CSolverStereoPosit::getTransformationWORLDtoLEFT on what they found; *pose as svi_stereo_posit_dev (synchronises) */
+int svi_track_pose_stereo_posit(svi_tracker* t, const uint8_t* active, const svi_posit_params* prm,
+                                const double* T_world_to_left_last, const double* t_imu,
+                                const double* T_world_to_left_estimate, const svi_track_result* out,
+                                svi_posit_result* pose);
 
 /* ------------------------------------------------------------------------------------------
  * Per-landmark refinement — replaces CLandmark::optimize / _getOptimizedLandmarkSTEREOUV (src/types/CLandmark.cpp:281-296,
@@ -423,6 +526,10 @@ typedef struct svi_ba_options {
     /* elimination order of the reduced camera system: 0 = nested dissection of the key-frame sequence (independent
      * chains factorised side by side), 1 = natural (ascending id: one chain) */
     int    chol_order;
+    /* record a HIP event pair around the Jacobian sweep (K2 + K3) of every linearisation inside the ordinary,
+     * non-synchronised LM loop (svi_ba_get_sweep_time); unlike `profile` nothing else is timed and the host still
+     * waits on the published trial scalars only */
+    int    sweep_events;
 } svi_ba_options;
 
 void svi_ba_options_default(svi_ba_options* o);
@@ -555,6 +662,10 @@ enum svi_ba_phase {
 int svi_ba_get_phase_times(svi_ba* ba, double ms[SVI_PH_COUNT], int64_t calls[SVI_PH_COUNT]);
 int svi_ba_reset_phase_times(svi_ba* ba);
 
+/* accumulated device milliseconds and launch count of the Jacobian sweep inside the LM loop since the last reset
+ * (options.sweep_events != 0 or options.profile != 0) */
+int svi_ba_get_sweep_time(svi_ba* ba, double* ms_total, int64_t* calls);
+
 /* sizes of the device structures, for roofline accounting */
 typedef struct svi_ba_stats {
     int64_t n_poses, n_poses_free, n_landmarks, n_landmarks_local;
@@ -586,6 +697,10 @@ int svi_ba_debug_reduced_system(svi_ba* ba, double lambda, double* S, double* g,
 int svi_ba_debug_time_sweep(svi_ba* ba, int reps, double* ms_avg);
 /* the same for one of the two kernels of the sweep: which = 1 landmark-major (K2), 2 pose-major (K3) */
 int svi_ba_debug_time_sweep_part(svi_ba* ba, int reps, int which, double* ms_avg);
+
+/* the sweep with cold caches: before each of the `reps` sweeps a scratch buffer of `evict_bytes` (>= 2 x the 256 MiB
+ * Infinity Cache to be sure) is overwritten, every sweep sits between its own event pair; mean ms per sweep */
+int svi_ba_debug_time_sweep_cold(svi_ba* ba, int reps, size_t evict_bytes, double* ms_avg);
 
 /* timing probe of the diagonal-tile Cholesky kernel (tile 48 or 96): mean ms per launch over `reps`
  * launches, truncated after phase `stop_after` (0 full, 1 pivot sweep, 2 +scale/store, 3 +diagonal

@@ -38,6 +38,19 @@ class TrackCamera(C.Structure):
                 ("width", C.c_double), ("height", C.c_double)]
 
 
+class TrackLandmarks(C.Structure):
+    _fields_ = [("n", C.c_int), ("xyz_world", vp), ("kp_size", vp), ("last_disparity", vp), ("uv_reference", vp), ("dp_index", vp),
+                ("last_desc_left", vp), ("last_desc_right", vp), ("ref_desc_left", vp)]
+
+
+class TrackResult(C.Structure):
+    _fields_ = [("status", vp), ("stage", vp), ("uv_left", vp), ("uv_right", vp), ("xyz_left", vp), ("desc_left", vp), ("desc_right", vp)]
+
+
+EXTRACT_FN = C.CFUNCTYPE(C.c_int, vp, C.c_int, vp, vp, vp, C.c_int, C.c_int64, vp, vp, vp, C.POINTER(C.c_int64), vp)
+DETECT_FN = C.CFUNCTYPE(C.c_int, vp, C.c_int, vp, vp, C.c_int, C.c_int64, vp, vp, C.POINTER(C.c_int64), vp)
+
+
 class TrackStereoParams(C.Structure):
     _fields_ = [("f", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("duR_flipped", C.c_double),
                 ("min_disparity", C.c_double), ("depth_min", C.c_double), ("depth_max", C.c_double),
@@ -84,7 +97,7 @@ class BaOptions(C.Structure):
                 ("max_depth_xyz_l2", C.c_double), ("max_depth_uvdepth_l2", C.c_double),
                 ("max_depth_uvdisp_l2", C.c_double), ("sane_position_l2", C.c_double),
                 ("device", C.c_int), ("stream", vp), ("rank", C.c_int), ("n_ranks", C.c_int),
-                ("profile", C.c_int), ("chol_tile", C.c_int), ("chol_order", C.c_int)]
+                ("profile", C.c_int), ("chol_tile", C.c_int), ("chol_order", C.c_int), ("sweep_events", C.c_int)]
 
 
 class BaStats(C.Structure):
@@ -108,6 +121,8 @@ SIGNATURES = {
     "svi_matcher_destroy": (C.c_int, [vp]),
     "svi_matcher_sync": (C.c_int, [vp]),
     "svi_matcher_stream": (vp, [vp]),
+    "svi_matcher_set_gate_path": (C.c_int, [vp, C.c_int]),
+    "svi_debug_shader_clock_mhz": (C.c_int, [vp, f64p]),
     "svi_match_hamming256": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.POINTER(Gate), C.c_int, vp, vp]),
     "svi_match_hamming256_dev": (C.c_int, [vp, vp, C.c_int, vp, C.c_int, C.c_int, C.POINTER(Gate), C.c_int, vp, vp]),
     "svi_match_clouds_dev": (C.c_int, [vp, vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int, vp, vp]),
@@ -132,6 +147,20 @@ SIGNATURES = {
     "svi_brief_integral_dev": (C.c_int, [vp, C.c_int, vp]),
     "svi_brief_compute_dev": (C.c_int, [vp, C.c_int, vp, vp, vp, C.c_int, C.c_int64, vp, vp, vp, i64p]),
     "svi_posit_params_default": (None, [C.POINTER(PositParams)]),
+    "svi_tracker_create": (C.c_int, [vp, C.POINTER(TrackCamera), C.POINTER(vp)]),
+    "svi_tracker_destroy": (C.c_int, [vp]),
+    "svi_tracker_set_brief": (C.c_int, [vp, vp]),
+    "svi_tracker_set_extractor": (C.c_int, [vp, EXTRACT_FN, vp]),
+    "svi_tracker_set_detector": (C.c_int, [vp, DETECT_FN, vp, C.c_int64]),
+    "svi_tracker_plan": (C.c_int, [vp, f64p, f64p, C.c_int, C.c_double, C.POINTER(TrackLandmarks)]),
+    "svi_tracker_set_descriptors": (C.c_int, [vp, vp, vp, vp]),
+    "svi_tracker_records": (C.c_int, [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(C.c_int64)]),
+    "svi_track_stage1": (C.c_int, [vp, vp, C.POINTER(TrackResult)]),
+    "svi_track_stage2": (C.c_int, [vp, vp, C.POINTER(TrackResult)]),
+    "svi_track_epipolar": (C.c_int, [vp, vp, C.POINTER(TrackResult)]),
+    "svi_track_manual": (C.c_int, [vp, vp, C.POINTER(TrackResult)]),
+    "svi_track_pose_stereo_posit": (C.c_int, [vp, vp, C.POINTER(PositParams), f64p, f64p, f64p, C.POINTER(TrackResult), C.POINTER(PositResult)]),
+    "svi_track_add_new_landmarks": (C.c_int, [vp, vp, vp, vp, C.c_int, C.POINTER(TrackResult)]),
     "svi_stereo_posit_dev": (C.c_int, [vp, C.POINTER(PositParams), f64p, f64p, f64p, vp, vp, vp, vp, C.c_int, C.POINTER(PositResult)]),
     "svi_landmark_params_default": (None, [C.POINTER(LandmarkParams)]),
     "svi_landmarks_optimize_dev": (C.c_int, [vp, C.POINTER(LandmarkParams), vp, vp, C.c_int, vp, vp, vp, vp, vp, C.c_int, vp, vp, vp, vp]),
@@ -177,6 +206,8 @@ SIGNATURES = {
     "svi_debug_chol_probe": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, f64p]),
     "svi_ba_debug_time_sweep": (C.c_int, [vp, C.c_int, f64p]),
     "svi_ba_debug_time_sweep_part": (C.c_int, [vp, C.c_int, C.c_int, f64p]),
+    "svi_ba_debug_time_sweep_cold": (C.c_int, [vp, C.c_int, C.c_size_t, f64p]),
+    "svi_ba_get_sweep_time": (C.c_int, [vp, f64p, i64p]),
 }
 
 _lib = None

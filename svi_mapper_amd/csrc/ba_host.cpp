@@ -950,8 +950,10 @@ int linearize(svi_ba* ba, bool read = true)
     BaDev& d = ba->d;
     hipStream_t s = ba->stream;
     PhaseTimer& t = ba->timer;
+    ba->sweep_timer.begin(0, s);
     t.begin(SVI_PH_LINEARIZE_LM, s);   ba_linearize_lm(d, ba->cur, s);   t.end(s);
     t.begin(SVI_PH_LINEARIZE_POSE, s); ba_linearize_pose(d, ba->cur, s); t.end(s);
+    ba->sweep_timer.end(s);
     t.begin(SVI_PH_POSE_EDGES, s);
     ba_linearize_aux(d, ba->cur, ba->opt.rank, s);
     ba_pose_finalize(d, ba->red_slot, ba->opt.rank, ba->opt.n_ranks, s);
@@ -1112,6 +1114,8 @@ int optimize_block(svi_ba* ba, int iterations, int* performed)
     // the estimates stay on the device; the host copy is refreshed by the first call that reads it (ensure_host)
     ba->host_stale = true;
     ba->timer.collect();
+    // the last trial's scalars have been read: every sweep of this block has completed, its events can be queried
+    ba->sweep_timer.collect();
     return SVI_OK;
 }
 
@@ -1167,6 +1171,7 @@ int svi_ba_create(const svi_ba_options* o, svi_ba** out)
         ba->own_stream = true;
     }
     ba->timer.on = o->profile != 0;
+    ba->sweep_timer.on = o->sweep_events != 0 && o->profile == 0;
     *out = ba;
     return SVI_OK;
 }
@@ -1178,6 +1183,7 @@ int svi_ba_destroy(svi_ba* ba)
     (void)hipStreamSynchronize(ba->stream);
     free_device(ba);
     ba->timer.release();
+    ba->sweep_timer.release();
     if (ba->own_stream) (void)hipStreamDestroy(ba->stream);
     delete ba;
     return SVI_OK;
@@ -1572,6 +1578,16 @@ int svi_ba_reset_phase_times(svi_ba* ba)
 {
     if (!ba) return fail(SVI_ERR_INVALID, "null handle");
     for (int i = 0; i < SVI_PH_COUNT; ++i) { ba->timer.ms[i] = 0.0; ba->timer.calls[i] = 0; }
+    ba->sweep_timer.ms[0] = 0.0; ba->sweep_timer.calls[0] = 0;
+    return SVI_OK;
+}
+
+int svi_ba_get_sweep_time(svi_ba* ba, double* ms_total, int64_t* calls)
+{
+    if (!ba) return fail(SVI_ERR_INVALID, "null handle");
+    const bool prof = ba->timer.on;
+    if (ms_total) *ms_total = prof ? ba->timer.ms[SVI_PH_LINEARIZE_LM] + ba->timer.ms[SVI_PH_LINEARIZE_POSE] : ba->sweep_timer.ms[0];
+    if (calls) *calls = prof ? ba->timer.calls[SVI_PH_LINEARIZE_LM] : ba->sweep_timer.calls[0];
     return SVI_OK;
 }
 
@@ -1671,6 +1687,31 @@ static int time_sweep_impl(svi_ba* ba, int reps, int which, double* ms_avg)
     return SVI_OK;
 }
 int svi_ba_debug_time_sweep(svi_ba* ba, int reps, double* ms_avg) { return time_sweep_impl(ba, reps, 0, ms_avg); }
+
+int svi_ba_debug_time_sweep_cold(svi_ba* ba, int reps, size_t evict_bytes, double* ms_avg)
+{
+    if (!ba || !ms_avg || reps < 1 || evict_bytes == 0) return fail(SVI_ERR_INVALID, "bad argument");
+    if (!ba->initialized) return fail(SVI_ERR_STATE, "debug tap before svi_ba_initialize");
+    SVI_HIP(hipSetDevice(ba->opt.device));
+    void* scratch = nullptr;
+    SVI_HIP(hipMalloc(&scratch, evict_bytes));
+    std::vector<hipEvent_t> ev((size_t)2 * reps);
+    for (auto& e : ev) SVI_HIP(hipEventCreate(&e));
+    for (int i = 0; i < reps; ++i) {
+        SVI_HIP(hipMemsetAsync(scratch, i & 0xFF, evict_bytes, ba->stream)); // pushes the sweep's operands out of L2 and the Infinity Cache
+        SVI_HIP(hipEventRecord(ev[2 * i], ba->stream));
+        ba_linearize_lm(ba->d, ba->cur, ba->stream);
+        ba_linearize_pose(ba->d, ba->cur, ba->stream);
+        SVI_HIP(hipEventRecord(ev[2 * i + 1], ba->stream));
+    }
+    SVI_HIP(hipStreamSynchronize(ba->stream));
+    double total = 0.0;
+    for (int i = 0; i < reps; ++i) { float t = 0.f; SVI_HIP(hipEventElapsedTime(&t, ev[2 * i], ev[2 * i + 1])); total += t; }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    (void)hipFree(scratch);
+    *ms_avg = total / reps;
+    return SVI_OK;
+}
 int svi_ba_debug_time_sweep_part(svi_ba* ba, int reps, int which, double* ms_avg)
 {
     if (which != 1 && which != 2) return fail(SVI_ERR_INVALID, "which must be 1 (K2) or 2 (K3)");

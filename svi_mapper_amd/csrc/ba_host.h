@@ -81,6 +81,7 @@ struct svi_ba {
     svi_allreduce_fn ar = nullptr;
     void* ar_user = nullptr;
     svi::PhaseTimer timer;
+    svi::PhaseTimer sweep_timer; // phase 0 = K2 + K3 inside the LM loop (options.sweep_events)
 };
 
 // host copy of the estimates in step with the device (ba_host.cpp); collective with several ranks when it has to act

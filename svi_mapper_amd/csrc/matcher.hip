@@ -351,6 +351,13 @@ int svi_matcher_sync(svi_matcher* m)
 
 void* svi_matcher_stream(svi_matcher* m) { return m ? static_cast<void*>(m->stream) : nullptr; }
 
+int svi_matcher_set_gate_path(svi_matcher* m, int path)
+{
+    if (!m || path < 0 || path > 1) return svi::fail(SVI_ERR_INVALID, "svi_matcher_set_gate_path: path must be 0 or 1");
+    m->gate_path = path;
+    return SVI_OK;
+}
+
 static int launch_match(svi_matcher* m, const uint8_t* q, int nq, const uint8_t* t, int nt, int batch,
                         const svi_gate* gate, int cutoff, int32_t* out_idx, int32_t* out_dist,
                         bool fuse, double f, double cx, double cy, double dur, double min_disp, double* out_xyz,
@@ -380,7 +387,7 @@ static int launch_match(svi_matcher* m, const uint8_t* q, int nq, const uint8_t*
     if (fuse) { a.finv = 1.0 / f; a.cx = cx; a.cy = cy; a.dur = dur; a.min_disp = min_disp; a.out_xyz = out_xyz; a.out_ok = out_ok; }
 
     // Gated call on a small pool: sort the pool by row in LDS and visit only the rows a query can match.
-    if (gate && !t_seg && nt > 0 && nt <= kBucketPool && gate->v_tol >= 0.0f && gate->v_tol <= 8.0f) {
+    if (gate && !t_seg && nt > 0 && nt <= kBucketPool && gate->v_tol >= 0.0f && gate->v_tol <= 8.0f && m->gate_path != 1) {
         const size_t lds = (size_t)nt * (32 + 8 + 4);
         static bool attr = false;
         if (!attr) {
@@ -432,6 +439,38 @@ static int launch_match(svi_matcher* m, const uint8_t* q, int nq, const uint8_t*
         hipLaunchKernelGGL(k_match_finalize, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, m->stream, a, batch);
         SVI_HIP(hipGetLastError());
     }
+    return SVI_OK;
+}
+
+// Shader clock while every CU runs integer VALU work (the matcher's roofline denominator: 64 lane-ops per CU and cycle):
+// block 0 brackets a fixed dependent xor / popcount chain with the shader cycle counter and the 100 MHz constant counter.
+__global__ __launch_bounds__(256) void k_clock_probe(int iters, unsigned* sink, double* out)
+{
+    unsigned x = threadIdx.x * 2654435761u + blockIdx.x, acc = 0;
+    const long long c0 = clock64(), w0 = wall_clock64();
+    for (int i = 0; i < iters; ++i) {
+#pragma unroll
+        for (int k = 0; k < 8; ++k) { x ^= x << 13; x ^= x >> 17; x ^= x << 5; acc += __popc(x); }
+    }
+    const long long c1 = clock64(), w1 = wall_clock64();
+    if (acc == 0x7fffffffu) sink[0] = acc; // keeps the chain alive
+    if (blockIdx.x == 0 && threadIdx.x == 0) { out[0] = (double)(c1 - c0); out[1] = (double)(w1 - w0); }
+}
+
+int svi_debug_shader_clock_mhz(svi_matcher* m, double* mhz)
+{
+    if (!m || !mhz) return svi::fail(SVI_ERR_INVALID, "null argument");
+    SVI_HIP(hipSetDevice(m->device));
+    if (int rc = m->scratch.reserve(64)) return rc;
+    double* out = m->scratch.as<double>();
+    unsigned* sink = reinterpret_cast<unsigned*>(out + 4);
+    hipLaunchKernelGGL(k_clock_probe, dim3(m->n_cu * 8), dim3(256), 0, m->stream, 20000, sink, out);
+    hipLaunchKernelGGL(k_clock_probe, dim3(m->n_cu * 8), dim3(256), 0, m->stream, 20000, sink, out); // the second one runs on ramped clocks
+    SVI_HIP(hipGetLastError());
+    double h[2] = {0, 0};
+    SVI_HIP(hipMemcpyAsync(h, out, sizeof(h), hipMemcpyDeviceToHost, m->stream));
+    SVI_HIP(hipStreamSynchronize(m->stream));
+    *mhz = h[1] > 0 ? h[0] / (h[1] / 100.0) : 0.0; // wall_clock64 ticks at 100 MHz
     return SVI_OK;
 }
 

@@ -9,6 +9,7 @@ struct svi_matcher {
     hipStream_t stream = nullptr;
     bool        own_stream = false;
     int         n_cu = 256;
+    int         gate_path = 0; // svi_matcher_set_gate_path
     svi::DevBuf keys;      // split-mode packed minima
     svi::DevBuf scratch;   // host-pointer entry points stage through here
     svi::DevBuf track;     // tracker.hip: fundamental matrices + uploaded transforms of one plan call

@@ -65,6 +65,15 @@ class HammingMatcher:
     def stream(self):
         return self._lib.svi_matcher_stream(self._h)
 
+    def set_gate_path(self, path):
+        """0: gated calls on a small pool bucket it by image row (default); 1: the gate as a per-pair predicate of the scan"""
+        check(self._lib.svi_matcher_set_gate_path(self._h, int(path)), "svi_matcher_set_gate_path")
+
+    def shader_clock_mhz(self):
+        v = C.c_double(0)
+        check(self._lib.svi_debug_shader_clock_mhz(self._h, C.byref(v)), "svi_debug_shader_clock_mhz")
+        return v.value
+
     def synchronize(self):
         check(self._lib.svi_matcher_sync(self._h), "svi_matcher_sync")
 

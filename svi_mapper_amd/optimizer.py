@@ -30,13 +30,14 @@ class BundleAdjuster:
     """LM bundle adjustment with the reference's graph rules, on one MI355X (or one shard of a node)."""
 
     def __init__(self, fx, fy, cx, cy, baseline_m, device=0, stream=None, rank=0, n_ranks=1, profile=False,
-                 chol_tile=96, **lm):
+                 chol_tile=96, sweep_events=False, **lm):
         self._lib = _capi.load_library()
         o = BaOptions()
         self._lib.svi_ba_options_default(C.byref(o))
         o.fx, o.fy, o.cx, o.cy, o.baseline_m = fx, fy, cx, cy, baseline_m
         o.device, o.rank, o.n_ranks, o.profile, o.chol_tile = device, rank, n_ranks, int(profile), chol_tile
         o.stream = stream
+        o.sweep_events = int(sweep_events)
         for k, v in lm.items():
             if not hasattr(o, k):
                 raise TypeError("unknown option %r" % k)
@@ -271,6 +272,19 @@ class BundleAdjuster:
         else:
             check(self._lib.svi_ba_debug_time_sweep(self._h, int(reps), C.byref(v)), "svi_ba_debug_time_sweep")
         return v.value
+
+    def time_sweep_cold(self, reps=20, evict_bytes=640 << 20):
+        """mean ms of the sweep with L2 / Infinity Cache flushed before every launch (each sweep between its own events)"""
+        v = C.c_double(0)
+        check(self._lib.svi_ba_debug_time_sweep_cold(self._h, int(reps), int(evict_bytes), C.byref(v)), "svi_ba_debug_time_sweep_cold")
+        return v.value
+
+    def sweep_time(self):
+        """(total ms, launches) of the Jacobian sweep inside the LM loop since the last reset (sweep_events / profile)"""
+        ms = C.c_double(0)
+        n = C.c_int64(0)
+        check(self._lib.svi_ba_get_sweep_time(self._h, C.byref(ms), C.byref(n)), "svi_ba_get_sweep_time")
+        return ms.value, n.value
 
     def edge_jacobians(self):
         n = self.stats().n_edges_proj

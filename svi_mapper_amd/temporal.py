@@ -13,11 +13,14 @@ Reference shapes mirrored here (src/core/CFundamentalMatcher.{h,cpp})
 
 The reference walks one landmark at a time and uses exceptions for control flow; here every step runs for all
 landmarks of a frame in one launch and the exceptions become per-landmark status codes (SVI_TRK_MATCH_*).
-BRIEF extraction / GFTT detection are OpenCV's and stay with the caller: `extractor(side, roi, seg, kp_uv)` is
-called with device tensors (roi n x 4 f32, seg n+1 i32, kp_uv total x 2 f32 in ROI coordinates) and returns
-(seg', kp_uv', desc') - the key points it kept (OpenCV drops those too close to the ROI border) and their
-32-byte descriptors.  All tensors are torch CUDA tensors; only data_ptr() crosses the boundary and torch itself is
-used for boolean masks, index lists / gathers and three exactly rounded float32 expressions (4s, 8s+1, kp + 4s).
+The cascades themselves (stage 1 -> 2 -> 3, masks, hand-overs) run behind the C ABI (csrc/track_cascade.hip:
+svi_track_stage1 / _stage2 / _epipolar / _manual / _pose_stereo_posit / _add_new_landmarks); this file only marshals
+tensors and adapts Python callables to the library's extractor / detector callbacks.
+GFTT detection is OpenCV's and stays with the caller; BRIEF extraction is either the built-in BriefExtractor (no callback:
+the frame is tracked without leaving the device) or a caller's `extractor(side, roi, seg, kp_uv)`, called with device tensors
+(roi n x 4 f32, seg n+1 i32, kp_uv total x 2 f32 in ROI coordinates) and returning (seg', kp_uv', desc') - the key points it
+kept (OpenCV drops those too close to the ROI border) and their 32-byte descriptors.  `detector(side, rect)` gets the n
+search rectangles (corners) and returns (seg, kp_uv in rectangle coordinates).
 """
 import ctypes as C
 
@@ -26,8 +29,8 @@ import torch
 
 from . import _capi
 from ._capi import LandmarkParams, PositParams, PositResult
-from ._capi import (MATCH_OK, MATCH_SKIPPED, TRACK_RECORD_FIELDS, TRACK_RECORD_SIZE, TRK_EPI_NO_MOTION, TRK_EPI_OK, TRK_FOV_LEFT,
-                    TRK_FOV_RIGHT, TrackCamera, TrackStereoParams, check)
+from ._capi import (MATCH_OK, MATCH_SKIPPED, TRACK_RECORD_FIELDS, TRACK_RECORD_SIZE, TrackCamera, TrackLandmarks, TrackResult,
+                    TrackStereoParams, check)
 from .matcher import HammingMatcher
 
 RECORD_DTYPE = np.dtype(TRACK_RECORD_FIELDS)
@@ -35,6 +38,26 @@ RECORD_DTYPE = np.dtype(TRACK_RECORD_FIELDS)
 
 def _p(t):
     return None if t is None else t.data_ptr()
+
+
+class _Alias:
+    """__cuda_array_interface__ carrier: lets torch alias library-owned device memory without a copy"""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": typestr, "data": (int(ptr), False), "version": 2,
+                                         "strides": None}
+
+
+_TYPESTR = {torch.float32: "<f4", torch.int32: "<i4", torch.uint8: "|u1", torch.float64: "<f8"}
+
+
+def _alias(ptr, shape, dtype, device):
+    n = 1
+    for x in shape:
+        n *= int(x)
+    if n == 0 or not ptr:
+        return torch.empty(tuple(shape), dtype=dtype, device=device)
+    return torch.as_tensor(_Alias(ptr, shape, _TYPESTR[dtype]), device=device)
 
 
 class StereoCamera:
@@ -94,8 +117,14 @@ class StageResult:
         self.desc_left = torch.zeros((n, 32), dtype=torch.uint8, device=device)
         self.desc_right = torch.zeros((n, 32), dtype=torch.uint8, device=device)
 
+        self.stage = torch.zeros((n,), dtype=torch.int8, device=device)
+
     def ok(self):
         return self.status == MATCH_OK
+
+    def c_struct(self):
+        return TrackResult(_p(self.status), _p(self.stage), _p(self.uv_left), _p(self.uv_right), _p(self.xyz_left), _p(self.desc_left),
+                           _p(self.desc_right))
 
 
 class FundamentalMatcher:
@@ -119,6 +148,117 @@ class FundamentalMatcher:
         # the library launches on the matcher's own stream: order torch's work on the current stream around it
         self._ext = torch.cuda.ExternalStream(self.matcher.stream, device=self.device)
         self._dummy = torch.zeros(64, dtype=torch.uint8, device=self.device)
+        h = C.c_void_p()
+        check(self._lib.svi_tracker_create(self._h, C.byref(self._cam), C.byref(h)), "svi_tracker_create")
+        self._trk = h
+        self._bound = (None, None)   # the (extractor, detector) the tracker handle is bound to, with their ctypes thunks kept alive
+        self._thunks = ()
+        self._frame = None           # tensors of the planned frame (kept alive while the tracker holds their pointers)
+        self.detector_capacity = 1 << 20
+
+    def close(self):
+        if getattr(self, "_trk", None):
+            self._lib.svi_tracker_destroy(self._trk)
+            self._trk = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- callbacks: Python callables behind svi_extract_fn / svi_detect_fn -------------------------------------------
+    def _bind(self, extractor, detector):
+        if self._bound == (extractor, detector):
+            return
+        dev = self.device
+        thunks = []
+        if isinstance(extractor, BriefExtractor):
+            if extractor.matcher is not self.matcher:
+                raise ValueError("the BriefExtractor must be built on this matcher (same stream)")
+            check(self._lib.svi_tracker_set_brief(self._trk, extractor._h), "svi_tracker_set_brief")
+        elif extractor is not None:
+            def extract_cb(user, side, roi, seg, kp_uv, n, total_in, seg_out, kp_out, desc_out, total_out, stream):
+                try:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
+                        seg_t = _alias(seg, (n + 1,), torch.int32, dev)
+                        total = int(seg_t[-1].item()) if n else 0
+                        s2, k2, d2 = extractor("left" if side == 0 else "right", _alias(roi, (n, 4), torch.float32, dev), seg_t,
+                                               _alias(kp_uv, (total, 2), torch.float32, dev))
+                        kept = int(k2.shape[0])
+                        if kept > total_in:
+                            return 2
+                        _alias(seg_out, (n + 1,), torch.int32, dev).copy_(s2.to(torch.int32))
+                        if kept:
+                            _alias(kp_out, (kept, 2), torch.float32, dev).copy_(k2)
+                            _alias(desc_out, (kept, 32), torch.uint8, dev).copy_(d2)
+                        torch.cuda.current_stream(dev).synchronize()
+                    total_out[0] = kept
+                    return 0
+                except Exception:  # noqa: BLE001  (an exception must not unwind through the C frames)
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            thunks.append(_capi.EXTRACT_FN(extract_cb))
+            check(self._lib.svi_tracker_set_extractor(self._trk, thunks[-1], None), "svi_tracker_set_extractor")
+        if detector is not None:
+            def detect_cb(user, side, rect, active, n, cap, seg_out, kp_out, total_out, stream):
+                try:
+                    with torch.cuda.stream(torch.cuda.ExternalStream(stream, device=dev)):
+                        seg_d, kp_d = detector("left" if side == 0 else "right", _alias(rect, (n, 4), torch.float32, dev))
+                        act = _alias(active, (n,), torch.uint8, dev).bool()
+                        cnt = (seg_d[1:] - seg_d[:-1]).long()
+                        if bool((cnt[~act] != 0).any()):    # rows that do not run must stay empty
+                            keep = torch.repeat_interleave(act, cnt)
+                            kp_d = kp_d[keep]
+                            cnt = torch.where(act, cnt, torch.zeros_like(cnt))
+                            seg_d = torch.cat([torch.zeros(1, dtype=torch.long, device=dev), torch.cumsum(cnt, 0)]).to(torch.int32)
+                        total = int(kp_d.shape[0])
+                        if total > cap:
+                            return 2
+                        _alias(seg_out, (n + 1,), torch.int32, dev).copy_(seg_d.to(torch.int32))
+                        if total:
+                            _alias(kp_out, (total, 2), torch.float32, dev).copy_(kp_d)
+                        torch.cuda.current_stream(dev).synchronize()
+                    total_out[0] = total
+                    return 0
+                except Exception:  # noqa: BLE001
+                    import traceback
+                    traceback.print_exc()
+                    return 1
+            thunks.append(_capi.DETECT_FN(detect_cb))
+            check(self._lib.svi_tracker_set_detector(self._trk, thunks[-1], None, int(self.detector_capacity)), "svi_tracker_set_detector")
+        else:
+            check(self._lib.svi_tracker_set_detector(self._trk, _capi.DETECT_FN(0), None, 0), "svi_tracker_set_detector")
+        self._bound = (extractor, detector)
+        self._thunks = tuple(thunks)
+
+    def _descriptors(self, last_left, last_right, ref_left):
+        keep = []
+        ptrs = []
+        for t in (last_left, last_right, ref_left):
+            if t is None:
+                ptrs.append(None)
+                continue
+            t = t.contiguous()
+            if t.dtype != torch.uint8 or not t.is_cuda:
+                raise ValueError("descriptors must be uint8 CUDA tensors")
+            keep.append(t)
+            ptrs.append(self._q(t))
+        self._desc_keep = keep
+        check(self._lib.svi_tracker_set_descriptors(self._trk, *ptrs), "svi_tracker_set_descriptors")
+
+    def _run(self, fn, name, plan, active):
+        if self._frame is None or plan is not self._frame:
+            raise ValueError("the cascades run on the most recently planned frame")
+        res = StageResult(plan.n, self.device)
+        if active is not None:
+            active = active.to(torch.uint8).contiguous()
+        rs = res.c_struct()
+        self._enter()
+        check(fn(self._trk, _p(active), C.byref(rs)), name)
+        self._leave()
+        return res
 
     # ------------------------------------------------------------------------------------------
     def _enter(self):
@@ -147,15 +287,21 @@ class FundamentalMatcher:
                       (uv_reference, torch.float64), (dp_index, torch.int32)):
             if t.dtype != dt or not t.is_cuda or not t.is_contiguous():
                 raise ValueError("plan: inputs must be contiguous CUDA tensors of the documented dtypes")
-        records = self._empty((n, TRACK_RECORD_SIZE), torch.uint8)
-        seg = self._empty((n + 1,), torch.int32)
-        total = C.c_int64(0)
+        lm = TrackLandmarks(n, _p(xyz_world), _p(kp_size), _p(last_disparity), _p(uv_reference), _p(dp_index), None, None, None)
         self._enter()
-        check(self._lib.svi_track_plan_dev(self._h, C.byref(self._cam), T.ctypes.data_as(_capi.f64p), dp.ctypes.data_as(_capi.f64p) if len(dp) else None,
-                                           len(dp), float(motion_scaling), _p(xyz_world), _p(kp_size), _p(last_disparity), _p(uv_reference),
-                                           _p(dp_index), n, _p(records), _p(seg), C.byref(total)), "svi_track_plan_dev")
+        check(self._lib.svi_tracker_plan(self._trk, T.ctypes.data_as(_capi.f64p), dp.ctypes.data_as(_capi.f64p) if len(dp) else None, len(dp),
+                                         float(motion_scaling), C.byref(lm)), "svi_tracker_plan")
+        rec_p, seg_p, total = C.c_void_p(), C.c_void_p(), C.c_int64(0)
+        check(self._lib.svi_tracker_records(self._trk, C.byref(rec_p), C.byref(seg_p), C.byref(total)), "svi_tracker_records")
+        with torch.cuda.stream(self._ext):
+            # the tracker owns the plan; the harness works on copies (they outlive the next frame's plan)
+            records = _alias(rec_p.value, (n, TRACK_RECORD_SIZE), torch.uint8, self.device).clone()
+            seg = _alias(seg_p.value, (n + 1,), torch.int32, self.device).clone()
         self._leave()
-        return TrackPlan(records, seg, total.value, kp_size)
+        plan = TrackPlan(records, seg, total.value, kp_size)
+        self._frame = plan
+        self._frame_keep = (xyz_world, kp_size, last_disparity, uv_reference, dp_index)
+        return plan
 
     # ---- stage 3 sampling ------------------------------------------------------------------------
     def epipolar_samples(self, plan, depth, sel=None):
@@ -243,203 +389,75 @@ class FundamentalMatcher:
         self._leave()
         return idx, dist, status, uv_other, xyz
 
-    # ---- the stereo half shared by all stages -----------------------------------------------------
-    def _stereo(self, extractor, search_in_left, kp_size, search_range, ref_desc, last_other, uv_ref, topleft, active, cutoff_other,
-                other_inclusive):
-        seg, st_range, roi, total = self.stereo_range(search_in_left, uv_ref, topleft, kp_size, search_range, active)
-        pool_uv = self.stereo_candidates(search_in_left, kp_size, seg, total)
-        seg2, pool_uv2, pool = extractor("left" if search_in_left else "right", roi, seg, pool_uv)
-        run = (st_range == MATCH_OK).to(torch.uint8)
-        prm = self.stereo_params(search_in_left, cutoff_other, other_inclusive)
-        idx, dist, status, uv_other, xyz = self.stereo_verify(prm, ref_desc, last_other, uv_ref, topleft, seg2, pool, pool_uv2, run)
-        status = torch.where(st_range != MATCH_OK, st_range, status)
-        won = (seg2[:-1] + idx.clamp(min=0)).long()
-        desc_other = pool[won.clamp(max=max(pool.shape[0] - 1, 0))] if pool.shape[0] else torch.zeros((ref_desc.shape[0], 32), dtype=torch.uint8, device=self.device)
-        return status, uv_other, xyz, desc_other
-
-    @staticmethod
-    def _store(res, rows, status, uv_l, uv_r, xyz, d_l, d_r):
-        res.status[rows] = status
-        good = status == MATCH_OK
-        g = rows[good]
-        res.uv_left[g] = uv_l[good]
-        res.uv_right[g] = uv_r[good]
-        res.xyz_left[g] = xyz[good]
-        res.desc_left[g] = d_l[good]
-        res.desc_right[g] = d_r[good]
-
-    # ---- stage 1 (:391-486) ------------------------------------------------------------------------
+    # ---- the cascades: one call each across the boundary (csrc/track_cascade.hip) -------------------------------------------
     def track_stage1(self, plan, extractor, last_desc_left, last_desc_right, active=None):
-        """Descriptor at the projected pixel, LEFT first then RIGHT, followed by the stereo search in the other
-        image.  Returns a StageResult over all plan.n landmarks; rows that fail keep their last failure code."""
-        n = plan.n
-        res = StageResult(n, self.device)
-        st = plan.status()
-        both = ((st & TRK_FOV_LEFT) != 0) & ((st & TRK_FOV_RIGHT) != 0)              # :389
-        run = both if active is None else both & active.bool()
-        todo = torch.nonzero(run).flatten()
-        rec32 = plan.records.view(torch.float32)
-        for side in (0, 1):
-            if todo.numel() == 0:
-                break
-            sel = todo.to(torch.int32)
-            kp = plan.kp_size[todo]
-            # one key point at (4s, 4s) of the (8s+1)^2 ROI around the projection (:395-400 / :449-454)
-            uv_ref, topleft, _ = self.handover(side, plan, sel)
-            col = (RECORD_DTYPE.fields["s1_roi_left" if side == 0 else "s1_roi_right"][1]) // 4
-            roi_xy = rec32[todo][:, col:col + 2]
-            side_len = 8 * kp + 1
-            roi = torch.stack([roi_xy[:, 0], roi_xy[:, 1], side_len, side_len], 1).contiguous()
-            seg1 = torch.arange(todo.numel() + 1, dtype=torch.int32, device=self.device)
-            kp_uv = torch.stack([4 * kp, 4 * kp], 1).contiguous()
-            seg_e, kp_e, desc_e = extractor("left" if side == 0 else "right", roi, seg1, kp_uv)
-            last_here = (last_desc_left if side == 0 else last_desc_right)[todo].contiguous()
-            last_there = (last_desc_right if side == 0 else last_desc_left)[todo].contiguous()
-            idx, dist, status = self.get_match(last_here, None, seg_e, desc_e, self.cutoff_stage1)     # :404 / :453
-            found = status == MATCH_OK
-            pos = (seg_e[:-1] + idx.clamp(min=0)).long().clamp(max=max(desc_e.shape[0] - 1, 0))
-            desc_here = desc_e[pos] if desc_e.shape[0] else torch.zeros((todo.numel(), 32), dtype=torch.uint8, device=self.device)
-            rng = rec32[todo][:, RECORD_DTYPE.fields["search_range"][1] // 4].contiguous()
-            s_status, uv_other, xyz, desc_other = self._stereo(extractor, side, kp.contiguous(), rng, desc_here.contiguous(), last_there, uv_ref,
-                                                               topleft, found.to(torch.uint8), self.cutoff_stage1, 1)     # :423 / :473
-            status = torch.where(found, s_status, status)
-            # the measurement keeps the PROJECTED pixel of the image the descriptor was found in (:427 / :477)
-            uvL = plan.records.view(torch.float32)[todo][:, RECORD_DTYPE.fields["uv_left"][1] // 4:][:, :2]
-            uvR = plan.records.view(torch.float32)[todo][:, RECORD_DTYPE.fields["uv_right"][1] // 4:][:, :2]
-            if side == 0:
-                self._store(res, todo, status, uvL, uv_other, xyz, desc_here, desc_other)
-            else:
-                self._store(res, todo, status, uv_other, uvR, xyz, desc_other, desc_here)
-            todo = todo[status != MATCH_OK]
-        return res
+        """Stage 1 (:391-486): descriptor at the projected pixel, LEFT first then RIGHT, followed by the stereo search in the
+        other image.  Returns a StageResult over all plan.n landmarks; rows that fail keep their last failure code."""
+        self._bind(extractor, self._bound[1])
+        self._descriptors(last_desc_left, last_desc_right, None)
+        return self._run(self._lib.svi_track_stage1, "svi_track_stage1", plan, active)
 
-    # ---- stage 2 (:489-709, :1042-1290) --------------------------------------------------------------
     def track_stage2(self, plan, detector, extractor, last_desc_left, last_desc_right, active=None):
-        """Regional search: `detector(side, rect)` (rect n x 4 f32: the search rectangle corners) returns the ragged
-        key points it found (seg, kp_uv in search-rectangle coordinates); they are shifted by (4s,4s) and described
-        inside the grown rectangle (:533-534), matched against the last descriptor (cut-off 50) and verified in
-        the other image."""
-        n = plan.n
-        res = StageResult(n, self.device)
-        st = plan.status()
-        both = ((st & TRK_FOV_LEFT) != 0) & ((st & TRK_FOV_RIGHT) != 0)
-        run = both if active is None else both & active.bool()
-        todo = torch.nonzero(run).flatten()
-        rec32 = plan.records.view(torch.float32)
-        for side in (0, 1):
-            if todo.numel() == 0:
-                break
-            sel = todo.to(torch.int32)
-            kp = plan.kp_size[todo].contiguous()
-            name = "left" if side == 0 else "right"
-            c_rect = RECORD_DTYPE.fields["s2_" + name][1] // 4
-            c_ext = RECORD_DTYPE.fields["s2_ext_" + name][1] // 4
-            rect = rec32[todo][:, c_rect:c_rect + 4].contiguous()
-            corners = torch.round(rec32[todo][:, c_ext:c_ext + 4])   # cv::Rect( Point2f, Point2f ): corners are cvRound()ed
-            ext = torch.stack([corners[:, 0], corners[:, 1], corners[:, 2] - corners[:, 0], corners[:, 3] - corners[:, 1]], 1).contiguous()
-            seg_d, kp_d = detector(name, rect)
-            owner = torch.repeat_interleave(torch.arange(todo.numel(), device=self.device), (seg_d[1:] - seg_d[:-1]).long())
-            kp_shift = (kp_d + (4 * kp)[owner][:, None]).contiguous()                                   # :533
-            seg_e, kp_e, desc_e = extractor(name, ext, seg_d, kp_shift)
-            last_here = (last_desc_left if side == 0 else last_desc_right)[todo].contiguous()
-            last_there = (last_desc_right if side == 0 else last_desc_left)[todo].contiguous()
-            idx, dist, status = self.get_match(last_here, None, seg_e, desc_e, self.cutoff_stage2)     # :540-545
-            uv_ref, topleft, ok = self.handover(2 + side, plan, sel, seg_e, kp_e, idx)
-            found = (status == MATCH_OK) & ok.bool()
-            status = torch.where((status == MATCH_OK) & ~ok.bool(), torch.full_like(status, _capi.MATCH_RANGE), status)   # "out of tracking range"
-            pos = (seg_e[:-1] + idx.clamp(min=0)).long().clamp(max=max(desc_e.shape[0] - 1, 0))
-            desc_here = desc_e[pos] if desc_e.shape[0] else torch.zeros((todo.numel(), 32), dtype=torch.uint8, device=self.device)
-            rng = rec32[todo][:, RECORD_DTYPE.fields["search_range"][1] // 4].contiguous()
-            s_status, uv_other, xyz, desc_other = self._stereo(extractor, side, kp, rng, desc_here.contiguous(), last_there, uv_ref, topleft,
-                                                               found.to(torch.uint8), self.cutoff_stage2, 0)               # :573 / :691
-            status = torch.where(found, s_status, status)
-            if side == 0:
-                self._store(res, todo, status, uv_ref, uv_other, xyz, desc_here, desc_other)
-            else:
-                self._store(res, todo, status, uv_other, uv_ref, xyz, desc_other, desc_here)
-            todo = todo[status != MATCH_OK]
-        return res
+        """Stage 2 (:489-709): `detector(side, rect)` (rect n x 4 f32: the search rectangle corners) returns the ragged key
+        points it found (seg, kp_uv in search-rectangle coordinates); they are shifted by (4s,4s) and described inside the grown
+        rectangle (:533-534), matched against the last descriptor (cut-off 50) and verified in the other image."""
+        self._bind(extractor, detector)
+        self._descriptors(last_desc_left, last_desc_right, None)
+        return self._run(self._lib.svi_track_stage2, "svi_track_stage2", plan, active)
 
-    # ---- stage 3 (:847-1030) ---------------------------------------------------------------------------
-    def track_epipolar(self, plan, extractor, last_desc_left, ref_desc_left, active=None):
-        """Sampling along the clipped epipolar line (depth 0, then 2 for the landmarks that found nothing), _getMatch
-        with the relative (50) and original (100) cut-offs, then _addMeasurementToLandmarkLEFT: the stereo search in
-        RIGHT without a descriptor check.  Landmarks without SVI_TRK_EPI_OK report SKIPPED."""
-        n = plan.n
-        res = StageResult(n, self.device)
-        st = plan.status()
-        run = (st & TRK_EPI_OK) != 0
-        if active is not None:
-            run = run & active.bool()
-        todo = torch.nonzero(run).flatten()
-        depth = 0
-        rec32 = plan.records.view(torch.float32)
-        while todo.numel() > 0:
-            sel = todo.to(torch.int32)
-            seg, sample_uv, roi = self.epipolar_samples(plan, depth, sel)
-            seg_e, kp_e, desc_e = extractor("left", roi, seg, sample_uv)
-            ref = last_desc_left[todo].contiguous()
-            orig = ref_desc_left[todo].contiguous()
-            idx, dist, status = self.get_match(ref, orig, seg_e, desc_e, self.cutoff_stage3, self.cutoff_original)
-            found = status == MATCH_OK
-            uv_ref, topleft, ok = self.handover(4, plan, sel, seg_e, kp_e, idx, roi)
-            pos = (seg_e[:-1] + idx.clamp(min=0)).long().clamp(max=max(desc_e.shape[0] - 1, 0))
-            desc_here = desc_e[pos] if desc_e.shape[0] else torch.zeros((todo.numel(), 32), dtype=torch.uint8, device=self.device)
-            kp = plan.kp_size[todo].contiguous()
-            rng = rec32[todo][:, RECORD_DTYPE.fields["search_range"][1] // 4].contiguous()
-            s_status, uv_other, xyz, desc_other = self._stereo(extractor, 0, kp, rng, desc_here.contiguous(), None, uv_ref, topleft,
-                                                               found.to(torch.uint8), -1, 0)
-            final = torch.where(found, s_status, status)
-            self._store(res, todo, final, uv_ref, uv_other, xyz, desc_here, desc_other)
-            # only an internal "no match" recurses (:2221-2233); a stereo failure after a match is final
-            if depth >= self.recursion_limit:
-                break
-            todo = todo[~found]
-            depth += self.recursion_step
-        return res
+    def track_epipolar(self, plan, extractor, last_desc_left, ref_desc_left, active=None, detector=None, last_desc_right=None):
+        """trackEpipolar (:794-1315): sampling along the clipped epipolar line (depth 0, then 2 for the landmarks that found
+        nothing), _getMatch with the relative (50) and original (100) cut-offs, then _addMeasurementToLandmarkLEFT: the stereo
+        search in RIGHT without a descriptor check.  Landmarks whose detection point has not moved have no epipolar line: with
+        a detector they are searched by stage 2 (:1026-1290).  Everything else without SVI_TRK_EPI_OK reports SKIPPED."""
+        self._bind(extractor, detector)
+        self._descriptors(last_desc_left, last_desc_right if last_desc_right is not None else last_desc_left, ref_desc_left)
+        return self._run(self._lib.svi_track_epipolar, "svi_track_epipolar", plan, active)
 
-    # ---- trackManual (:1366-2019): stage 1 -> stage 2 -> epipolar, each only for what the previous one lost ----------
     def track_manual(self, plan, detector, extractor, last_desc_left, last_desc_right, ref_desc_left, active=None):
-        """One StageResult; `stage` (int8: 1, 2, 3, 0 = none) tells which stage produced each measurement.  A landmark
-        outside the field of view of either camera is not tracked at all (:1415, :2008-2012)."""
-        r1 = self.track_stage1(plan, extractor, last_desc_left, last_desc_right, active)
-        tried = r1.status != MATCH_SKIPPED
-        lost1 = tried & (r1.status != MATCH_OK)
-        r2 = self.track_stage2(plan, detector, extractor, last_desc_left, last_desc_right, lost1.to(torch.uint8))
-        lost2 = lost1 & (r2.status != MATCH_OK)
-        r3 = self.track_epipolar(plan, extractor, last_desc_left, ref_desc_left, lost2.to(torch.uint8))
-        out = StageResult(plan.n, self.device)
-        out.stage = torch.zeros(plan.n, dtype=torch.int8, device=self.device)
-        out.status = torch.where(tried, r1.status, out.status)
-        for k, r in ((1, r1), (2, r2), (3, r3)):
-            ran = r.status != MATCH_SKIPPED
-            out.status = torch.where(ran, r.status, out.status)
-            good = r.status == MATCH_OK
-            for name in ("uv_left", "uv_right", "xyz_left", "desc_left", "desc_right"):
-                getattr(out, name)[good] = getattr(r, name)[good]
-            out.stage[good] = k
-        return out
+        """trackManual (:1366-2019): stage 1 -> stage 2 -> epipolar, each only for what the previous one lost.  One StageResult;
+        `stage` (int8: 1, 2, 3, 0 = none) tells which stage produced each measurement.  A landmark outside the field of view of
+        either camera is not tracked at all (:1415, :2008-2012)."""
+        self._bind(extractor, detector)
+        self._descriptors(last_desc_left, last_desc_right, ref_desc_left)
+        return self._run(self._lib.svi_track_manual, "svi_track_manual", plan, active)
 
-    # ---- addNewLandmarks (:109-175) ------------------------------------------------------------------------------------
+    def pose_stereo_posit(self, plan, detector, extractor, last_desc_left, last_desc_right, solver, T_last, t_imu, T_estimate, active=None):
+        """getPoseStereoPosit (:340-760): stage 1 -> stage 2 over the active (bIsOptimal) landmarks and the frame pose from what
+        they found, in one call.  -> (StageResult, PositResult); xyz_world of the plan call feeds the solver."""
+        self._bind(extractor, detector)
+        self._descriptors(last_desc_left, last_desc_right, None)
+        if self._frame is None or plan is not self._frame:
+            raise ValueError("the cascades run on the most recently planned frame")
+        res = StageResult(plan.n, self.device)
+        rs = res.c_struct()
+        pose = PositResult()
+        Tl = np.ascontiguousarray(T_last, np.float64).reshape(12)
+        Te = np.ascontiguousarray(T_estimate, np.float64).reshape(12)
+        ti = np.ascontiguousarray(t_imu, np.float64).reshape(3)
+        if active is not None:
+            active = active.to(torch.uint8).contiguous()
+        self._enter()
+        check(self._lib.svi_track_pose_stereo_posit(self._trk, _p(active), C.byref(solver.params), Tl.ctypes.data_as(_capi.f64p),
+                                                    ti.ctypes.data_as(_capi.f64p), Te.ctypes.data_as(_capi.f64p), C.byref(rs), C.byref(pose)),
+              "svi_track_pose_stereo_posit")
+        self._leave()
+        return res, pose
+
     def add_new_landmarks(self, extractor, uv_left, kp_size, desc_left):
-        """Stereo partner + triangulation of freshly detected key points: getPointTriangulatedInRIGHTFull with the search
-        window of CTriangulator::fMinimumSearchRangePixels = 60 (no depth gate, no second descriptor check).
+        """addNewLandmarks (:83-193): stereo partner + triangulation of freshly detected key points: getPointTriangulatedInRIGHTFull
+        with the search window of CTriangulator::fMinimumSearchRangePixels = 60 (no depth gate, no second descriptor check).
         uv_left n x 2 f32, kp_size n f32, desc_left n x 32 u8 (the detector / extractor output on the LEFT image)."""
+        self._bind(extractor, self._bound[1])
         n = uv_left.shape[0]
         res = StageResult(n, self.device)
-        half = 4 * kp_size
-        topleft = torch.stack([torch.clamp_min(uv_left[:, 0] - 60.0 - half, 0.0), uv_left[:, 1] - half], 1).contiguous()   # :119-120
-        prm = self.stereo_params(0, -1, 0)
-        prm.depth_min, prm.depth_max = -1.0e300, 1.0e300
-        seg, st_range, roi, total = self.stereo_range(0, uv_left.contiguous(), topleft, kp_size.contiguous())
-        pool_uv = self.stereo_candidates(0, kp_size.contiguous(), seg, total)
-        seg2, pool_uv2, pool = extractor("right", roi, seg, pool_uv)
-        run = (st_range == MATCH_OK).to(torch.uint8)
-        idx, dist, status, uv_other, xyz = self.stereo_verify(prm, desc_left.contiguous(), None, uv_left.contiguous(), topleft, seg2, pool, pool_uv2, run)
-        status = torch.where(st_range != MATCH_OK, st_range, status)
-        won = (seg2[:-1] + idx.clamp(min=0)).long()
-        desc_other = pool[won.clamp(max=max(pool.shape[0] - 1, 0))] if pool.shape[0] else torch.zeros((n, 32), dtype=torch.uint8, device=self.device)
-        self._store(res, torch.arange(n, device=self.device), status, uv_left, uv_other, xyz, desc_left, desc_other)
+        if n == 0:
+            return res
+        uv_left, kp_size, desc_left = uv_left.contiguous(), kp_size.contiguous(), desc_left.contiguous()
+        rs = res.c_struct()
+        self._enter()
+        check(self._lib.svi_track_add_new_landmarks(self._trk, _p(uv_left), _p(kp_size), _p(desc_left), n, C.byref(rs)), "svi_track_add_new_landmarks")
+        self._leave()
         return res
 
 

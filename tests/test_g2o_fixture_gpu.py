@@ -26,7 +26,9 @@ def _pair(svi, oracle):
 def test_loaded_graph_is_the_file(svi, oracle):
     g, o, lit = _pair(svi, oracle)
     assert g.num_poses == o.num_poses == 4 and g.num_landmarks == o.num_landmarks == 13
-    assert g.num_edges == o.num_edges == len(lit["proj"]) + 3 + 4 + 1
+    assert o.num_edges == g.num_edges == len(lit["proj"])       # (projection edges)
+    st = g.stats()
+    assert (st.n_edges_se3, st.n_edges_accel, st.n_edges_lmlm) == (3, 4, 1)
     ids_g, T_g = g.get_poses()
     ids_o, T_o = o.get_poses()
     assert np.array_equal(ids_g, ids_o)

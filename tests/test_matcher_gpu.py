@@ -44,6 +44,20 @@ def test_c2_gated_bit_exact(matcher, oracle):
     assert (idx < 0).sum() > 0  # and some queries have no candidate under the gate
 
 
+def test_c2_gate_as_per_pair_predicate(matcher, oracle):
+    """SURVEY 8d-ii quotes pairs/s with the gate evaluated per pair: that path (svi_matcher_set_gate_path 1) and the default
+    row-bucket path give the oracle's indices and distances alike"""
+    c2 = synth.make_descriptor_pair()
+    ridx, rdist = oracle.match_hamming256(c2["q"], c2["t"], c2["gate"], c2["cutoff"])
+    try:
+        matcher.set_gate_path(1)
+        idx, dist = matcher.match_arrays(c2["q"], c2["t"], c2["gate"], c2["cutoff"])
+    finally:
+        matcher.set_gate_path(0)
+    np.testing.assert_array_equal(idx, ridx)
+    np.testing.assert_array_equal(dist, rdist)
+
+
 def test_ties_pick_lowest_index(matcher):
     rng = np.random.default_rng(5)
     q = _rand_desc(rng, 70)
