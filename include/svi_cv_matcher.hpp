@@ -7,12 +7,18 @@
 // The class follows the plug-in pattern the reference already uses for its own matcher,
 // cv::CBTreeMatcher (src/vision/CBTreeMatcher.h:13-155): same overridden virtuals, k = 1 only.
 //
-// Header-only; compiled only where OpenCV is available (it is not in the build image of this
-// repository, so this file is not part of the test suite - see INTEGRATION.md).
+// The reference calls the 2-Mat overload m_pMatcher->match( query, pool, matches ) at all 11 sites; OpenCV implements it as
+// clone( true ) -> add( pool ) -> match( query ): clone() therefore SHARES the GPU handle (stream, device buffers) with the
+// matcher it was cloned from - no GPU resource is created or destroyed per call - and keeps the device it was built for.
+//
+// Header-only; OpenCV is not in the build image of this repository: tests/test_adapter_headers.py compiles it against
+// minimal stand-in declarations of the OpenCV names it uses (tests/stubs/opencv2: a syntax / override check, it pins
+// nothing); see INTEGRATION.md.
 #pragma once
 #include <opencv2/core/core.hpp>
 #include <opencv2/features2d/features2d.hpp>
 
+#include <memory>
 #include <stdexcept>
 #include <vector>
 
@@ -22,16 +28,22 @@ namespace svi {
 
 class HammingMatcherGPU : public cv::DescriptorMatcher {
 public:
-    explicit HammingMatcherGPU(int device = 0)
+    explicit HammingMatcherGPU(int device = 0) : device_(device)
     {
-        if (svi_matcher_create(device, nullptr, &m_) != SVI_OK) throw std::runtime_error(svi_last_error());
+        svi_matcher* m = nullptr;
+        if (svi_matcher_create(device, nullptr, &m) != SVI_OK) throw std::runtime_error(svi_last_error());
+        m_ = std::shared_ptr<svi_matcher>(m, [](svi_matcher* p) { svi_matcher_destroy(p); });
     }
-    ~HammingMatcherGPU() override { svi_matcher_destroy(m_); }
-    HammingMatcherGPU(const HammingMatcherGPU&) = delete;
-    HammingMatcherGPU& operator=(const HammingMatcherGPU&) = delete;
+    ~HammingMatcherGPU() override = default;
 
     bool isMaskSupported() const override { return false; }
-    cv::Ptr<cv::DescriptorMatcher> clone(bool = false) const override { return cv::makePtr<HammingMatcherGPU>(); }
+    // shares the handle; the train collection is copied unless emptyTrainData (cv::BFMatcher::clone does the same)
+    cv::Ptr<cv::DescriptorMatcher> clone(bool emptyTrainData = false) const override
+    {
+        cv::Ptr<HammingMatcherGPU> c(new HammingMatcherGPU(*this));
+        if (emptyTrainData) c->clear();
+        return c;
+    }
 
 protected:
     // called by cv::DescriptorMatcher::match(query, train, matches) with k = 1 after add(train)
@@ -49,7 +61,7 @@ protected:
             if (t.empty()) continue;
             const cv::Mat tc = t.isContinuous() ? t : t.clone();
             // 16-byte alignment of cv::Mat data is guaranteed by OpenCV's allocator
-            if (svi_match_hamming256(m_, qc.ptr<uint8_t>(), q.rows, tc.ptr<uint8_t>(), t.rows, nullptr, 257, idx.data(), dist.data()) != SVI_OK)
+            if (svi_match_hamming256(m_.get(), qc.ptr<uint8_t>(), q.rows, tc.ptr<uint8_t>(), t.rows, nullptr, 257, idx.data(), dist.data()) != SVI_OK)
                 throw cv::Exception(0, svi_last_error(), "knnMatchImpl", __FILE__, __LINE__);
             for (int i = 0; i < q.rows; ++i) {
                 if (idx[i] < 0) continue;
@@ -67,7 +79,9 @@ protected:
     }
 
 private:
-    svi_matcher* m_ = nullptr;
+    HammingMatcherGPU(const HammingMatcherGPU&) = default;   // for clone(): same handle, same device, copied train collection
+    std::shared_ptr<svi_matcher> m_;
+    int device_ = 0;
 };
 
 } // namespace svi

@@ -362,3 +362,56 @@ def test_large_frame_properties(torch, fm):
     idx, dist, st = idx.cpu().numpy(), dist.cpu().numpy(), st.cpu().numpy()
     assert np.all(st == 0) and np.all(dist == 0) and np.all(idx <= pick - pseg[:-1])
     assert np.array_equal(pool[pseg[:-1] + idx], q)
+
+
+def test_track_epipolar_without_motion_falls_back_to_stage2(oracle, cam, torch, fm):
+    """trackEpipolar (:841-1290): a detection point that has not moved since (|t|^2 == 0) has no epipolar line - its landmarks are
+    searched by stage 2 instead, everything else along its line"""
+    sc = ts.Scene(n=300, seed=29)
+    # detection point 0 sits exactly at the current pose: the relative transform is the identity
+    sc.dp_T = np.array(sc.dp_T, np.float64).copy()
+    sc.dp_T[0] = ts.inv12(sc.T_est_w2l)
+    # ... bit for bit: t_rel = ((R0 t0 + R1 t1) + R2 t2) + t_est in the reference's operand order (:800-806) must be exactly 0
+    A, td = sc.T_est_w2l.copy(), sc.dp_T[0][9:]
+    for i in range(3):
+        A[9 + i] = -(((A[3 * i] * td[0]) + (A[3 * i + 1] * td[1])) + (A[3 * i + 2] * td[2]))
+    sc.T_est_w2l = A
+    rec, seg = cpu_plan(oracle, cam, sc)
+    still = (rec["status"] & 4) != 0
+    assert still.sum() > 20 and (~still).sum() > 20
+    plan = gpu_plan(torch, fm, sc)
+    om = oracle.OracleFundamentalMatcher(cam, sc.stereo_dict())
+    ext, det = sc.make_extractor(torch, "cuda"), sc.make_detector(torch, "cuda")
+    ll, lr, rf = dev(torch, sc.last_left), dev(torch, sc.last_right), dev(torch, sc.ref_desc)
+    got = fm.track_epipolar(plan, ext, ll, rf, detector=det, last_desc_right=lr)
+    s3 = om.epipolar(rec, sc.kp_size, sc.extract_one, sc.last_left, sc.ref_desc)
+    s2 = om.stage2(rec, sc.kp_size, sc.detect_one, sc.extract_one, sc.last_left, sc.last_right)
+    want = [b if still[i] else a for i, (a, b) in enumerate(zip(s3, s2))]
+    st = check_stage(got, want, sc.n)
+    stage = got.stage.cpu().numpy()
+    assert set(stage[still & (st == 0)].tolist()) == {2} and set(stage[~still & (st == 0)].tolist()) == {3}
+    # without a detector the landmarks of the still detection point are simply not searched
+    got = fm.track_epipolar(plan, ext, ll, rf)
+    assert (got.status.cpu().numpy()[still] == 8).all()
+
+
+def test_cascade_entry_points_reject_bad_calls(torch, fm, svi):
+    sc = ts.Scene(n=32, seed=2)
+    plan_old = gpu_plan(torch, fm, sc)
+    plan = gpu_plan(torch, fm, sc)
+    ext = sc.make_extractor(torch, "cuda")
+    ll, lr = dev(torch, sc.last_left), dev(torch, sc.last_right)
+    with pytest.raises(ValueError):
+        fm.track_stage1(plan_old, ext, ll, lr)          # not the frame the tracker holds
+    with pytest.raises(svi.SviError) as e:
+        fm.track_stage2(plan, None, ext, ll, lr)        # stage 2 without a detector
+    assert e.value.status == 4
+    lib = svi.load_library()
+    assert lib.svi_track_manual(None, None, None) == 1
+    assert lib.svi_tracker_create(None, None, None) == 1
+    # an extractor that fails must fail the call, not crash it
+    def broken(side, roi, seg, kp_uv):
+        raise RuntimeError("extractor failure (expected in this test)")
+    with pytest.raises(svi.SviError):
+        fm.track_stage1(plan, broken, ll, lr)
+    assert (fm.track_stage1(plan, ext, ll, lr).status != 8).any()   # the handle is still usable
