@@ -71,7 +71,7 @@ class ViStream:
         self.T_l2w = []
         pos = np.zeros(3)
         for i in range(n_frames):
-            R = _rot_y(yaw[i]) @ _rot_x(PITCH + 0.02 * np.sin(i / 23.0)) @ _rot_z(0.015 * np.cos(i / 31.0))
+            R = _rot_y(yaw[i]) @ _rot_x(-(PITCH + 0.02 * np.sin(i / 23.0))) @ _rot_z(0.015 * np.cos(i / 31.0))
             self.T_l2w.append(pack(R, pos.copy()))
             pos = pos + _rot_y(yaw[i]) @ np.array([0.0, 0.0, step]) + np.array([0.0, 0.002 * np.sin(i / 7.0), 0.0])
         # multi-scale smooth random texture + fine noise, tiled over the ground
@@ -132,9 +132,10 @@ class ViStream:
 class OnlineTracker:
     """the bookkeeping of CTrackerSVI around the hot path, landmark state as device tensors (capacity `cap`)"""
 
-    def __init__(self, stream, device_index=0, cap=4096, target_visible=500, min_visible=300, seed=1):
+    def __init__(self, stream, device_index=0, cap=None, target_visible=500, min_visible=300, seed=1):
         self.s = stream
         self.dev = stream.device
+        cap = cap or 4096 + 40 * stream.n_frames     # every landmark ever created keeps its row (ids stay stable for the graph)
         self.cap, self.target_visible, self.min_visible = cap, target_visible, min_visible
         self.rng = np.random.default_rng(seed)
         cam = temporal.StereoCamera(P_LEFT, P_RIGHT, W, H)
@@ -212,7 +213,7 @@ class OnlineTracker:
         uv = uv[self.rng.permutation(len(uv))[:want]]
         uv_d = torch.tensor(uv, device=self.dev)
         P, lam = self.s.ground_point(T_l2w_true, uv_d)
-        good = (lam > 0.5) & (lam < 25.0)
+        good = (lam > 0.5) & (lam < 7.0)      # disparity >= 7 px: farther ground is too coarsely triangulated with this baseline
         uv_d, P = uv_d[good], P[good]
         n = uv_d.shape[0]
         if n == 0:
@@ -334,9 +335,14 @@ class OnlineTracker:
         self.brief.set_image("left", images[0])
         self.brief.set_image("right", images[1])
         n = self.n_used
-        # constant-velocity prior (the IMU prior of CTrackerSVI::process)
+        # the motion prior of CTrackerSVI::process (:330-470): rotation increment from the gyroscope (here: the stream's true
+        # relative rotation plus a little noise), translation increment carried over from the last frame pair
         d = self._delta(self.T_w2l, self.T_prev)
-        Rd, td = d[:9].reshape(3, 3), d[9:]
+        g = self._delta(inv12(self.s.T_l2w[t]), inv12(self.s.T_l2w[t - 1]))
+        w = self.rng.normal(0, 2e-4, 3)
+        Rn = np.array([[1, -w[2], w[1]], [w[2], 1, -w[0]], [-w[1], w[0], 1]])
+        u_, _, vt_ = np.linalg.svd(Rn @ g[:9].reshape(3, 3))
+        Rd, td = u_ @ vt_, d[9:]
         T_est = pack(Rd @ self.T_w2l[:9].reshape(3, 3), Rd @ self.T_w2l[9:] + td)
         det = self._detector(inv12(self.s.T_l2w[t]))
         dp_T = np.array(self.dp_T)
