@@ -238,6 +238,28 @@ def bench_frontend(svi, reps=200):
     out["brief_extract_ms"] = timed(lambda: br("left", roi, g_seg, samples), 100)
     out["brief_keypoints_in"] = int(samples.shape[0])
     out["brief_keypoints_kept"] = int(kept[1].shape[0])
+    # a whole frame through the C++ cascades (CFundamentalMatcher::trackManual: stage 1 -> 2 -> 3 for every landmark, BRIEF on the
+    # device; the stage-2 detector is a stand-in on the device behind the Python callback shim, its cost is inside)
+    pts = {"left": d(sc.corners[0]), "right": d(sc.corners[1])}
+
+    def det(side, rect):
+        p = pts[side]
+        ul, lr = rect[:, :2].floor(), rect[:, 2:].floor()
+        inside = (p[None, :, 0] >= ul[:, None, 0]) & (p[None, :, 0] < lr[:, None, 0]) & (p[None, :, 1] >= ul[:, None, 1]) & (p[None, :, 1] < lr[:, None, 1])
+        idx = torch.nonzero(inside)
+        sg = torch.zeros(rect.shape[0] + 1, dtype=torch.int32, device=dev)
+        sg[1:] = torch.cumsum(inside.sum(1), 0)
+        return sg, (p[idx[:, 1]] - ul[idx[:, 0]]).contiguous()
+    img_r = d(brief_case.image(ts.H, ts.W, 2))
+    br.set_image("right", img_r)
+    lr_ = d(sc.last_right)
+    plan = fm.plan(*args)
+    res = fm.track_manual(plan, det, br, ll, lr_, rf)
+    out["track_manual_frame_ms"] = timed(lambda: fm.track_manual(plan, det, br, ll, lr_, rf), 30)
+    out["track_manual_frame_landmarks"] = int(plan.n)
+    out["track_manual_frame_rows_tracked"] = int((res.status != 8).sum())
+    out["track_stage1_frame_ms"] = timed(lambda: fm.track_stage1(plan, br, ll, lr_), 30)
+    out["track_epipolar_frame_ms"] = timed(lambda: fm.track_epipolar(plan, br, ll, rf), 30)
     # loop closure: 2000 query descriptors against 200 key frames x ~1500 descriptors
     nq, n_clouds = 2000, 200
     sizes = rng.integers(1000, 2000, n_clouds)
