@@ -158,7 +158,7 @@ int svi_ba_load_g2o(svi_ba* ba, const char* path)
         }
         if (rc != SVI_OK) return rc;
     }
-    return SVI_OK;
+    return edges_flush(ba);
 }
 
 int svi_ba_save_g2o(svi_ba* ba, const char* path)
@@ -221,10 +221,12 @@ int svi_ba_save_g2o(svi_ba* ba, const char* path)
         std::fprintf(f, "\n");
     }
     static const char* kTag[3] = {"EDGE_SE3_TRACKXYZ", "EDGE_PROJECT_DEPTH", "EDGE_PROJECT_DISPARITY"};
-    for (const HProj& e : ba->proj) {
-        std::fprintf(f, "%s %lld %lld %d %.17g %.17g %.17g", kTag[e.type], (long long)ba->poses[e.pose].id, (long long)ba->lms[e.lm].id,
-                     e.type == 0 ? 0 : 1, e.z[0], e.z[1], e.z[2]);
-        for (double x : e.info) std::fprintf(f, " %.17g", x);
+    for (size_t i = 0; i < ba->proj.size(); ++i) {
+        const EdgeStore& e = ba->proj;
+        const double* z = e.z(i);
+        std::fprintf(f, "%s %lld %lld %d %.17g %.17g %.17g", kTag[e.type(i)], (long long)ba->poses[e.pose[i]].id, (long long)ba->lms[e.lm[i]].id,
+                     e.type(i) == 0 ? 0 : 1, z[0], z[1], z[2]);
+        for (int q = 0; q < 6; ++q) std::fprintf(f, " %.17g", e.info(i)[q]);
         std::fprintf(f, "\n");
     }
     for (const HLL& e : ba->lmlm) {

@@ -46,6 +46,8 @@ void ba_configure_kernels(int TS);
 int chol_potrf_probe(int tile, int reps, int stop_after, double* ms);
 int chol_factor_solve(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n,
                       int* status, void* st);
+int build_structure(svi_ba* ba); // ba_structure.cpp
+int reupload_state(svi_ba* ba);
 
 void PhaseTimer::begin(int phase, hipStream_t s)
 {
@@ -87,36 +89,24 @@ namespace {
 
 const double kIdentity12[12] = {1, 0, 0, 0, 1, 0, 0, 0, 1, 0, 0, 0};
 
-void free_device(svi_ba* ba)
+// the device structures of the last initialize() are no longer valid (the buffers themselves stay: ba_structure.cpp re-uses them)
+void invalidate_device(svi_ba* ba)
 {
-    for (void* p : ba->allocs) (void)hipFree(p);
-    ba->allocs.clear();
-    if (ba->h_scal) { (void)hipHostFree(ba->h_scal); ba->h_scal = nullptr; }
-    if (ba->h_status) { (void)hipHostFree(ba->h_status); ba->h_status = nullptr; }
     ba->initialized = false;
     ba->d = BaDev{};
     ba->plan = CholPlan{};
 }
 
-template <class T> int dev_upload(svi_ba* ba, const std::vector<T>& h, const T** out, size_t min_elems = 1)
+void free_device(svi_ba* ba)
 {
-    const size_t n = std::max(h.size(), min_elems);
-    void* p = nullptr;
-    SVI_HIP(hipMalloc(&p, n * sizeof(T)));
-    ba->allocs.push_back(p);
-    if (!h.empty()) SVI_HIP(hipMemcpyAsync(p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ba->stream));
-    *out = static_cast<const T*>(p);
-    return SVI_OK;
-}
-template <class T> int dev_alloc(svi_ba* ba, size_t n, T** out, bool zero = true)
-{
-    void* p = nullptr;
-    n = std::max<size_t>(n, 1);
-    SVI_HIP(hipMalloc(&p, n * sizeof(T)));
-    ba->allocs.push_back(p);
-    if (zero) SVI_HIP(hipMemsetAsync(p, 0, n * sizeof(T), ba->stream));
-    *out = static_cast<T*>(p);
-    return SVI_OK;
+    for (auto& b : ba->pool) b.release();
+    ba->pool.clear();
+    ba->raw_log.release();
+    ba->raw_flags.release();
+    ba->raw_uploaded = 0; ba->raw_cap = 0;
+    if (ba->h_scal) { (void)hipHostFree(ba->h_scal); ba->h_scal = nullptr; }
+    if (ba->h_status) { (void)hipHostFree(ba->h_status); ba->h_status = nullptr; }
+    invalidate_device(ba);
 }
 
 #define SVI_TRY(x) do { int rc_ = (x); if (rc_ != SVI_OK) return rc_; } while (0)
@@ -129,764 +119,6 @@ int allreduce(svi_ba* ba, double* buf, size_t count)
     const int rc = ba->ar(ba->ar_user, buf, count, ba->stream);
     ba->timer.end(ba->stream);
     if (rc != 0) return fail(SVI_ERR_COMM, "all-reduce hook returned %d", rc);
-    return SVI_OK;
-}
-
-// ---------------------------------------------------------------------------------------------
-// structure analysis (g2o initializeOptimization + buildStructure equivalent)
-// ---------------------------------------------------------------------------------------------
-#define SVI_TIMING_MARK(k) do { if (dbg_t) { auto now_ = std::chrono::steady_clock::now(); fprintf(stderr, "build_structure: section %d starts at %.1f ms\n", k, std::chrono::duration<double, std::milli>(now_ - t_begin_).count()); } } while (0)
-int build_structure(svi_ba* ba)
-{
-    const bool dbg_t = getenv("SVI_DEBUG_PLAN") != nullptr;
-    const auto t_begin_ = std::chrono::steady_clock::now();
-    BaDev& d = ba->d;
-    const svi_ba_options& o = ba->opt;
-    d.fx = o.fx; d.fy = o.fy; d.cx = o.cx; d.cy = o.cy; d.cauchy_delta = o.cauchy_delta;
-    const int Pn = (int)ba->poses.size();
-    const int Ltot = (int)ba->lms.size();
-
-    SVI_TIMING_MARK(0);
-    // ---- vertex order: ascending id (g2o index mapping) ----
-    ba->pose_order.resize(Pn);
-    std::iota(ba->pose_order.begin(), ba->pose_order.end(), 0);
-    std::sort(ba->pose_order.begin(), ba->pose_order.end(), [&](int a, int b) { return ba->poses[a].id < ba->poses[b].id; });
-    std::vector<int> pose_slot(Pn), pose_red(Pn), red_slot;
-    for (int s = 0; s < Pn; ++s) pose_slot[ba->pose_order[s]] = s;
-    for (int s = 0; s < Pn; ++s) {
-        if (ba->poses[ba->pose_order[s]].fixed) pose_red[s] = -1;
-        else { pose_red[s] = (int)red_slot.size(); red_slot.push_back(s); }
-    }
-    const int Pf = (int)red_slot.size();
-    SVI_TIMING_MARK(1);
-    // ---- elimination order of the reduced camera system (nested dissection of the key-frame sequence) ----
-    // The reduced system of a trajectory is block-banded: in natural order its Cholesky is ONE chain of tile
-    // columns.  Cutting the sequence at separators as wide as the co-visibility span gives independent chains
-    // that are factorised side by side (ba_chol.hip processes all columns of one dependency level per launch).
-    // Every piece is a whole number of tiles except the top separator, which comes last and absorbs the
-    // remainder, so the identity padding stays at the end of the reduced index range.
-    ba->red_perm.resize(Pf);
-    std::iota(ba->red_perm.begin(), ba->red_perm.end(), 0);
-    {
-        const int TSo = o.chol_tile > 0 ? o.chol_tile : 96;
-        const int PBo = TSo / 6;
-        const int NTo = PBo > 0 ? (Pf + PBo - 1) / PBo : 0;
-        if (o.chol_order == 0 && PBo > 0 && NTo >= 6) {
-            // free poses of every landmark (natural reduced indices), pose-pose edges
-            std::vector<std::vector<int>> lm_red(Ltot);
-            for (const HProj& e : ba->proj) {
-                const int r = pose_red[pose_slot[e.pose]];
-                if (r >= 0 && !ba->lms[e.lm].fixed) lm_red[e.lm].push_back(r);
-            }
-            int span = 0; // largest |r_i - r_j| over coupled free poses
-            for (auto& v : lm_red) {
-                if (v.empty()) continue;
-                const auto mm = std::minmax_element(v.begin(), v.end());
-                span = std::max(span, *mm.second - *mm.first);
-            }
-            std::vector<std::pair<int, int>> pp;
-            for (const HSe3& e : ba->se3) {
-                const int ri = pose_red[pose_slot[e.i]], rj = pose_red[pose_slot[e.j]];
-                if (ri >= 0 && rj >= 0) { pp.push_back({ri, rj}); span = std::max(span, std::abs(ri - rj)); }
-            }
-            const int rem = Pf % PBo;
-            // elimination order for separators of `w` tiles; false if the sequence is too short for it
-            auto make_perm = [&](int w, std::vector<int>& perm) {
-                const int sep = w * PBo;
-                const int sep_top = rem == 0 ? sep : rem + PBo * ((std::max(sep - rem, 0) + PBo - 1) / PBo); // absorbs the remainder
-                if (Pf < sep_top + 4 * PBo) return false;
-                std::vector<std::pair<int, int>> pieces; // natural ranges in elimination order
-                std::function<void(int, int, int)> rec = [&](int a, int b, int wd) {
-                    const int len = b - a;
-                    if (len < wd + 2 * PBo) { if (len > 0) pieces.push_back({a, b}); return; }
-                    const int left = PBo * (((len - wd) / PBo) / 2);
-                    rec(a, a + left, sep);
-                    rec(a + left + wd, b, sep);
-                    pieces.push_back({a + left, a + left + wd});
-                };
-                rec(0, Pf, sep_top);
-                perm.assign(Pf, 0);
-                int pos = 0;
-                for (auto& pc : pieces) for (int r = pc.first; r < pc.second; ++r) perm[r] = pos++;
-                return true;
-            };
-            // which free poses share a landmark (lower triangle, natural reduced indices): computed once, every
-            // candidate order only re-maps it to tiles
-            const bool use_cpl = Pf <= 4096; // 16 MB at most; longer sequences walk the landmarks per candidate
-            std::vector<uint8_t> cpl(use_cpl ? (size_t)Pf * Pf : 0, 0);
-            if (use_cpl)
-                for (auto& lr : lm_red)
-                    for (size_t x = 0; x < lr.size(); ++x)
-                        for (size_t y = 0; y < lr.size(); ++y)
-                            if (lr[y] <= lr[x]) cpl[(size_t)lr[x] * Pf + lr[y]] = 1;
-            // dependency levels (= launches on the critical path) and filled tiles of an order
-            auto analyse = [&](const std::vector<int>& perm, int& depth, int& tiles) {
-                std::vector<uint8_t> z((size_t)NTo * NTo, 0);
-                for (int t = 0; t < NTo; ++t) z[(size_t)t * NTo + t] = 1;
-                if (use_cpl) {
-                    for (int ri = 0; ri < Pf; ++ri) { // pose-level coupling mapped to tiles
-                        const int tx = perm[ri] / PBo;
-                        const uint8_t* row = &cpl[(size_t)ri * Pf];
-                        for (int rj = 0; rj <= ri; ++rj)
-                            if (row[rj]) { const int ty = perm[rj] / PBo; z[(size_t)std::max(tx, ty) * NTo + std::min(tx, ty)] = 1; }
-                    }
-                } else {
-                    std::vector<int> v;
-                    for (auto& lr : lm_red) {
-                        v.clear();
-                        for (int r : lr) v.push_back(perm[r] / PBo);
-                        std::sort(v.begin(), v.end());
-                        v.erase(std::unique(v.begin(), v.end()), v.end());
-                        for (size_t x = 0; x < v.size(); ++x) for (size_t y = 0; y <= x; ++y) z[(size_t)v[x] * NTo + v[y]] = 1;
-                    }
-                }
-                for (auto& e : pp) { const int x = perm[e.first] / PBo, y = perm[e.second] / PBo; z[(size_t)std::max(x, y) * NTo + std::min(x, y)] = 1; }
-                std::vector<int> rows;
-                for (int k = 0; k < NTo; ++k) {
-                    rows.clear();
-                    for (int i = k + 1; i < NTo; ++i) if (z[(size_t)i * NTo + k]) rows.push_back(i);
-                    for (size_t x = 0; x < rows.size(); ++x) for (size_t y = 0; y <= x; ++y) z[(size_t)rows[x] * NTo + rows[y]] = 1;
-                }
-                std::vector<int> lev(NTo, 0);
-                depth = 0; tiles = 0;
-                for (int c = 0; c < NTo; ++c) {
-                    for (int q = 0; q < c; ++q) if (z[(size_t)c * NTo + q]) { lev[c] = std::max(lev[c], lev[q] + 1); }
-                    for (int q = 0; q <= c; ++q) tiles += z[(size_t)c * NTo + q];
-                    depth = std::max(depth, lev[c] + 1);
-                }
-            };
-            // candidates: natural order and separators of 1 .. ceil(span / tile) tiles (a separator narrower than the
-            // longest track still gives a valid order - the few tracks that cross it only add dependencies); keep the
-            // order with the fewest levels, then the fewest tiles
-            std::vector<int> best = ba->red_perm, cand;
-            int best_depth = 0, best_tiles = 0;
-            analyse(best, best_depth, best_tiles);
-            const int wmax = std::max(1, (span + PBo - 1) / PBo);
-            // (the symbolic analysis is cubic in the tile count: very long sequences only try the span-wide separator)
-            for (int w = (NTo > 256 ? std::min(wmax, 8) : 1); w <= wmax && w <= 8; ++w) {
-                if (!make_perm(w, cand)) break;
-                int dp = 0, tl = 0;
-                analyse(cand, dp, tl);
-                if (dp < best_depth || (dp == best_depth && tl < best_tiles)) { best = cand; best_depth = dp; best_tiles = tl; }
-            }
-            ba->red_perm = best;
-            for (int sl = 0; sl < Pn; ++sl) if (pose_red[sl] >= 0) pose_red[sl] = ba->red_perm[pose_red[sl]];
-            for (int sl = 0; sl < Pn; ++sl) if (pose_red[sl] >= 0) red_slot[pose_red[sl]] = sl;
-        }
-    }
-    ba->lm_order.resize(Ltot);
-    std::iota(ba->lm_order.begin(), ba->lm_order.end(), 0);
-    std::sort(ba->lm_order.begin(), ba->lm_order.end(), [&](int a, int b) { return ba->lms[a].id < ba->lms[b].id; });
-    std::vector<int> lm_slot(Ltot);
-    for (int s = 0; s < Ltot; ++s) lm_slot[ba->lm_order[s]] = s;
-
-    SVI_TIMING_MARK(2);
-    // ---- landmark sharding: contiguous slot ranges balanced by projection-edge count ----
-    std::vector<int64_t> deg(Ltot + 1, 0);
-    for (const HProj& e : ba->proj) deg[lm_slot[e.lm] + 1]++;
-    for (int s = 0; s < Ltot; ++s) deg[s + 1] += deg[s];
-    const int64_t Etot = (int64_t)ba->proj.size();
-    ba->E_total = Etot;
-    auto bound = [&](int r) -> int {
-        if (r <= 0) return 0;
-        if (r >= o.n_ranks) return Ltot;
-        const int64_t want = Etot * r / o.n_ranks;
-        int s = (int)(std::lower_bound(deg.begin(), deg.end(), want) - deg.begin());
-        return std::min(std::max(s, 0), Ltot);
-    };
-    ba->L0 = bound(o.rank);
-    ba->L1 = bound(o.rank + 1);
-    const int L0 = ba->L0, Ll = ba->L1 - ba->L0;
-
-    SVI_TIMING_MARK(3);
-    // ---- local projection edges, lm-major: (landmark, reduced pose [fixed first], slot) ----
-    std::vector<int> loc;
-    loc.reserve(ba->proj.size());
-    for (int i = 0; i < (int)ba->proj.size(); ++i) {
-        const int s = lm_slot[ba->proj[i].lm];
-        if (s >= L0 && s < ba->L1) loc.push_back(i);
-    }
-    const int E = (int)loc.size();
-    {
-        // order: landmark slot, then reduced pose index (fixed poses first), then pose slot, then insertion order -
-        // two stable counting sorts (by pose rank, then by landmark) instead of a comparison sort over 800 k records
-        std::vector<int> prank(Pn), pidx(Pn);
-        for (int s = 0; s < Pn; ++s) pidx[s] = s;
-        std::sort(pidx.begin(), pidx.end(), [&](int a, int b) { return pose_red[a] != pose_red[b] ? pose_red[a] < pose_red[b] : a < b; });
-        for (int r = 0; r < Pn; ++r) prank[pidx[r]] = r;
-        auto counting_sort = [](std::vector<int>& v, int n_keys, auto&& key) {
-            std::vector<int> cnt(n_keys + 1, 0), out(v.size());
-            for (int x : v) cnt[key(x) + 1]++;
-            for (int k = 0; k < n_keys; ++k) cnt[k + 1] += cnt[k];
-            for (int x : v) out[cnt[key(x)]++] = x;
-            v.swap(out);
-        };
-        counting_sort(loc, Pn, [&](int i) { return prank[pose_slot[ba->proj[i].pose]]; });
-        counting_sort(loc, ba->L1 - L0, [&](int i) { return lm_slot[ba->proj[i].lm] - L0; });
-    }
-    bool diag_info = true;
-    for (const HProj& e : ba->proj) if (e.info[1] != 0.0 || e.info[2] != 0.0 || e.info[4] != 0.0) { diag_info = false; break; }
-    const int planes = diag_info ? 3 : 6;
-    static const int kDiagIdx[3] = {0, 3, 5};
-    std::vector<int> e_pose(E), e_lm(E), e_orig(E), lm_ptr(Ll + 1, 0);
-    std::vector<uint8_t> e_flags(E);
-    const int np2 = (3 + planes + 1) / 2; // double2 planes of the packed [z | information | pad] record
-    std::vector<double> e_zi((size_t)2 * np2 * std::max(E, 1), 0.0);
-    auto zi_at = [&](std::vector<double>& a, int v, int k) -> double& { return a[2 * ((size_t)(v / 2) * E + k) + (v & 1)]; };
-    for (int k = 0; k < E; ++k) {
-        const HProj& e = ba->proj[loc[k]];
-        e_pose[k] = pose_slot[e.pose];
-        e_lm[k] = lm_slot[e.lm] - L0;
-        e_orig[k] = loc[k];
-        e_flags[k] = (uint8_t)((e.type & 3) | (e.robust ? kFlagRobust : 0));
-        for (int c = 0; c < 3; ++c) zi_at(e_zi, c, k) = e.z[c];
-        for (int c = 0; c < planes; ++c) zi_at(e_zi, 3 + c, k) = diag_info ? e.info[kDiagIdx[c]] : e.info[c];
-        lm_ptr[e_lm[k] + 1]++;
-    }
-    for (int l = 0; l < Ll; ++l) {
-        if (lm_ptr[l + 1] > kLmBlockEdges)
-            return fail(SVI_ERR_UNSUPPORTED, "landmark %lld has %d projection edges (limit %d)",
-                        (long long)ba->lms[ba->lm_order[L0 + l]].id, lm_ptr[l + 1], kLmBlockEdges);
-        lm_ptr[l + 1] += lm_ptr[l];
-    }
-    std::vector<int> lb_lm(1, 0);
-    for (int l = 0; l < Ll;) {
-        int l2 = l, edges = 0;
-        while (l2 < Ll && l2 - l < kLmBlockEdges && edges + (lm_ptr[l2 + 1] - lm_ptr[l2]) <= kLmBlockEdges) { edges += lm_ptr[l2 + 1] - lm_ptr[l2]; ++l2; }
-        lb_lm.push_back(l2);
-        l = l2;
-    }
-    const int n_lm_blocks = (int)lb_lm.size() - 1;
-    std::vector<uint8_t> lm_fixed(Ll);
-    for (int l = 0; l < Ll; ++l) lm_fixed[l] = (uint8_t)(ba->lms[ba->lm_order[L0 + l]].fixed ? 1 : 0);
-
-    SVI_TIMING_MARK(4);
-    // ---- pose-major copy: free poses only, (slot, landmark) ----
-    std::vector<int> pm;
-    pm.reserve(E);
-    for (int k = 0; k < E; ++k) if (pose_red[e_pose[k]] >= 0) pm.push_back(k);
-    { // stable counting sort by pose slot
-        std::vector<int> cnt(Pn + 1, 0), out(pm.size());
-        for (int x : pm) cnt[e_pose[x] + 1]++;
-        for (int k = 0; k < Pn; ++k) cnt[k + 1] += cnt[k];
-        for (int x : pm) out[cnt[e_pose[x]]++] = x;
-        pm.swap(out);
-    }
-    const int Epm = (int)pm.size();
-    std::vector<int> pm_lm(Epm), chunk_pose, chunk_begin, pose_chunk_ptr(Pn + 1, 0);
-    std::vector<uint8_t> pm_flags(Epm);
-    // the pose-major copy uses the same plane stride E as the lm-major arrays (the kernels share load_edge)
-    std::vector<double> pm_zi((size_t)2 * np2 * std::max(E, 1), 0.0);
-    for (int k = 0; k < Epm; ++k) {
-        const int src = pm[k];
-        pm_lm[k] = e_lm[src];
-        pm_flags[k] = e_flags[src];
-        for (int v = 0; v < 3 + planes; ++v) zi_at(pm_zi, v, k) = zi_at(e_zi, v, src);
-    }
-    {
-        int k = 0;
-        for (int s = 0; s < Pn; ++s) {
-            pose_chunk_ptr[s] = (int)chunk_pose.size();
-            int k2 = k;
-            while (k2 < Epm && e_pose[pm[k2]] == s) ++k2;
-            for (int b = k; b < k2; b += kPoseChunk) { chunk_pose.push_back(s); chunk_begin.push_back(b); }
-            k = k2;
-        }
-        pose_chunk_ptr[Pn] = (int)chunk_pose.size();
-        chunk_begin.push_back(Epm);
-    }
-    const int n_chunks = (int)chunk_pose.size();
-    // chunks are contiguous: the next chunk (same or next pose) starts exactly where this one ends,
-    // so chunk_begin[c+1] is the end of chunk c
-
-    SVI_TIMING_MARK(5);
-    // ---- pose-only / landmark-only edges ----
-    std::vector<int> se3_i, se3_j, acc_pose, ll_free;
-    std::vector<double> se3_Z, se3_info, acc_a, acc_info, ll_ref, ll_z, ll_info;
-    std::vector<uint8_t> se3_robust, ll_robust;
-    std::vector<std::vector<int>> pose_aux(Pn);
-    if (o.rank == 0) {
-        for (const HSe3& e : ba->se3) {
-            const int k = (int)se3_i.size();
-            se3_i.push_back(pose_slot[e.i]); se3_j.push_back(pose_slot[e.j]);
-            se3_Z.insert(se3_Z.end(), e.Z, e.Z + 12);
-            se3_info.insert(se3_info.end(), e.info, e.info + 21);
-            se3_robust.push_back((uint8_t)(e.robust ? 1 : 0));
-            pose_aux[pose_slot[e.i]].push_back((k << 2) | 0);
-            pose_aux[pose_slot[e.j]].push_back((k << 2) | 1);
-        }
-        for (const HAcc& e : ba->acc) {
-            const int k = (int)acc_pose.size();
-            acc_pose.push_back(pose_slot[e.pose]);
-            for (int r = 0; r < 3; ++r) acc_a.push_back(e.off[3 * r] * e.a[0] + e.off[3 * r + 1] * e.a[1] + e.off[3 * r + 2] * e.a[2]);
-            acc_info.insert(acc_info.end(), e.info, e.info + 6);
-            pose_aux[pose_slot[e.pose]].push_back((k << 2) | 2);
-        }
-    }
-    std::vector<int> pose_aux_ptr(Pn + 1, 0), pose_aux_ref;
-    for (int s = 0; s < Pn; ++s) {
-        pose_aux_ptr[s] = (int)pose_aux_ref.size();
-        pose_aux_ref.insert(pose_aux_ref.end(), pose_aux[s].begin(), pose_aux[s].end());
-    }
-    pose_aux_ptr[Pn] = (int)pose_aux_ref.size();
-    {
-        struct LL { int free_l; double ref[3], z[3], info[6]; uint8_t robust; };
-        std::vector<LL> v;
-        for (const HLL& e : ba->lmlm) {
-            const HLm &li = ba->lms[e.i], &lj = ba->lms[e.j];
-            if (!li.fixed && !lj.fixed)
-                return fail(SVI_ERR_UNSUPPORTED, "landmark-landmark edge %lld-%lld with two free ends (the reference fixes one, Cg2oOptimizer.cpp:445)",
-                            (long long)li.id, (long long)lj.id);
-            if (li.fixed && lj.fixed) continue;
-            LL x{};
-            const bool free_is_j = li.fixed != 0;
-            const HLm& fr = free_is_j ? lj : li;
-            const HLm& fx = free_is_j ? li : lj;
-            const int s = lm_slot[free_is_j ? e.j : e.i];
-            if (s < L0 || s >= ba->L1) continue;
-            x.free_l = s - L0;
-            (void)fr;
-            for (int c = 0; c < 3; ++c) { x.ref[c] = fx.p[c]; x.z[c] = free_is_j ? e.z[c] : -e.z[c]; }
-            memcpy(x.info, e.info, sizeof(x.info));
-            x.robust = (uint8_t)(e.robust ? 1 : 0);
-            v.push_back(x);
-        }
-        std::stable_sort(v.begin(), v.end(), [](const LL& a, const LL& b) { return a.free_l < b.free_l; });
-        for (const LL& x : v) {
-            ll_free.push_back(x.free_l);
-            ll_ref.insert(ll_ref.end(), x.ref, x.ref + 3);
-            ll_z.insert(ll_z.end(), x.z, x.z + 3);
-            ll_info.insert(ll_info.end(), x.info, x.info + 6);
-            ll_robust.push_back(x.robust);
-        }
-    }
-    std::vector<int> lm_ll_ptr(Ll + 1, 0);
-    for (int f : ll_free) lm_ll_ptr[f + 1]++;
-    for (int l = 0; l < Ll; ++l) lm_ll_ptr[l + 1] += lm_ll_ptr[l];
-
-    SVI_TIMING_MARK(6);
-    // ---- reduced system tiling (identical on every rank: derived from the GLOBAL graph) ----
-    int TS = o.chol_tile > 0 ? o.chol_tile : 96;
-    if (TS % 48 != 0 || TS > kMaxTile) return fail(SVI_ERR_INVALID, "chol_tile must be 48 or 96");
-    const int PB = TS / 6;
-    const int n = 6 * Pf;
-    const int NT = (n + TS - 1) / TS;
-    std::vector<uint8_t> nz((size_t)NT * NT, 0);
-    for (int t = 0; t < NT; ++t) nz[(size_t)t * NT + t] = 1;
-    {
-        // chunks touched by every landmark of the global graph
-        std::vector<std::vector<int>> lm_chunks(Ltot);
-        for (const HProj& e : ba->proj) {
-            const int r = pose_red[pose_slot[e.pose]];
-            if (r >= 0 && !ba->lms[e.lm].fixed) lm_chunks[e.lm].push_back(r / PB);
-        }
-        for (auto& v : lm_chunks) {
-            std::sort(v.begin(), v.end());
-            v.erase(std::unique(v.begin(), v.end()), v.end());
-            for (size_t a = 0; a < v.size(); ++a)
-                for (size_t b = 0; b <= a; ++b) nz[(size_t)v[a] * NT + v[b]] = 1;
-        }
-        for (const HSe3& e : ba->se3) {
-            const int ri = pose_red[pose_slot[e.i]], rj = pose_red[pose_slot[e.j]];
-            if (ri >= 0 && rj >= 0) { const int a = std::max(ri, rj) / PB, b = std::min(ri, rj) / PB; nz[(size_t)a * NT + b] = 1; }
-        }
-    }
-    const std::vector<uint8_t> nz_orig = nz; // tiles that receive Schur / pose-edge contributions (before fill-in)
-    // symbolic fill, right-looking over tile columns
-    std::vector<int> h_col_ptr(NT + 1, 0);
-    std::vector<std::pair<int, int>> col_rows;            // (k, i)
-    std::vector<int> upd_i, upd_j, upd_k;
-    for (int k = 0; k < NT; ++k) {
-        std::vector<int> rows;
-        for (int i = k + 1; i < NT; ++i) if (nz[(size_t)i * NT + k]) rows.push_back(i);
-        h_col_ptr[k] = (int)col_rows.size();
-        for (int i : rows) col_rows.push_back({k, i});
-        for (size_t a = 0; a < rows.size(); ++a)
-            for (size_t b = 0; b <= a; ++b) {
-                nz[(size_t)rows[a] * NT + rows[b]] = 1;
-                upd_i.push_back(rows[a]); upd_j.push_back(rows[b]); upd_k.push_back(k);
-            }
-    }
-    h_col_ptr[NT] = (int)col_rows.size();
-    // tile ids: the tiles with contributions first, pure fill-in tiles after them - only the former (and g) have to
-    // cross the all-reduce, the latter are zero on every rank until the factorisation fills them
-    std::vector<int> tile_map((size_t)NT * NT, -1), tile_ti, tile_tj;
-    for (int pass = 0; pass < 2; ++pass)
-        for (int j = 0; j < NT; ++j)
-            for (int i = j; i < NT; ++i)
-                if (nz[(size_t)i * NT + j] && (nz_orig[(size_t)i * NT + j] != 0) == (pass == 0)) {
-                    tile_map[(size_t)i * NT + j] = (int)tile_ti.size(); tile_ti.push_back(i); tile_tj.push_back(j);
-                }
-    const int n_tiles = (int)tile_ti.size();
-    int n_tiles_orig = 0;
-    for (size_t q = 0; q < nz_orig.size(); ++q) n_tiles_orig += nz_orig[q] ? 1 : 0;
-    std::vector<int> trsm_tile, trsm_row, diag_tile(NT);
-    for (auto& kr : col_rows) { trsm_tile.push_back(tile_map[(size_t)kr.second * NT + kr.first]); trsm_row.push_back(kr.second); }
-    for (int k = 0; k < NT; ++k) diag_tile[k] = tile_map[(size_t)k * NT + k];
-
-    // dependency levels: column c waits for every column p < c with a tile (c,p); all columns of one level are
-    // factorised by one launch (ba_chol.hip).  The update of a diagonal tile by a column of the level just below
-    // is applied by the workgroup that factorises it ("pre" list); every other update is grouped by TARGET tile
-    // and runs in the launch that follows its source column's level, one workgroup set per target with the
-    // sources in ascending order (no two workgroups ever write the same tile: deterministic without atomics).
-    std::vector<int> level(NT, 0);
-    for (int c = 0; c < NT; ++c)
-        for (int q = 0; q < c; ++q) if (tile_map[(size_t)c * NT + q] >= 0) level[c] = std::max(level[c], level[q] + 1);
-    const int n_steps = NT ? *std::max_element(level.begin(), level.end()) + 1 : 0;
-    std::vector<int> h_step_ptr(n_steps + 1, 0), step_col;
-    for (int st = 0; st < n_steps; ++st) {
-        h_step_ptr[st] = (int)step_col.size();
-        for (int c = 0; c < NT; ++c) if (level[c] == st) step_col.push_back(c);
-    }
-    h_step_ptr[n_steps] = (int)step_col.size();
-    std::vector<int> pre_ptr(NT + 1, 0), pre_tile, pre_col;
-    for (int c = 0; c < NT; ++c) {
-        pre_ptr[c] = (int)pre_tile.size();
-        for (int q = 0; q < c; ++q)
-            if (tile_map[(size_t)c * NT + q] >= 0 && level[q] == level[c] - 1) { pre_tile.push_back(tile_map[(size_t)c * NT + q]); pre_col.push_back(q); }
-    }
-    pre_ptr[NT] = (int)pre_tile.size();
-    // target-grouped updates per launch step
-    std::vector<int> h_tgt_ptr(n_steps + 1, 0), tgt_tile, tgt_row, tgt_pair_ptr(1, 0), pair_a, pair_b, pair_src;
-    double chol_flops = 0.0;
-    {
-        std::vector<std::vector<size_t>> by_step(n_steps);
-        for (size_t u = 0; u < upd_i.size(); ++u) {
-            const int i = upd_i[u], j = upd_j[u], q = upd_k[u];
-            if (i == j && level[q] == level[i] - 1) continue; // pre-update, done by the factorising workgroup
-            by_step[level[q] + 1].push_back(u);
-        }
-        for (int st = 0; st < n_steps; ++st) {
-            h_tgt_ptr[st] = (int)tgt_tile.size();
-            auto& v = by_step[st];
-            std::stable_sort(v.begin(), v.end(), [&](size_t x, size_t y) {
-                const int tx = tile_map[(size_t)upd_i[x] * NT + upd_j[x]], ty = tile_map[(size_t)upd_i[y] * NT + upd_j[y]];
-                return tx != ty ? tx < ty : upd_k[x] < upd_k[y];
-            });
-            int cur = -1;
-            for (size_t w = 0; w < v.size(); ++w) {
-                const size_t u = v[w];
-                const int tt = tile_map[(size_t)upd_i[u] * NT + upd_j[u]];
-                if (tt != cur) {
-                    tgt_tile.push_back(tt);
-                    tgt_row.push_back(upd_i[u] == upd_j[u] ? upd_i[u] : -1);
-                    tgt_pair_ptr.push_back(tgt_pair_ptr.back());
-                    cur = tt;
-                }
-                pair_a.push_back(tile_map[(size_t)upd_i[u] * NT + upd_k[u]]);
-                pair_b.push_back(tile_map[(size_t)upd_j[u] * NT + upd_k[u]]);
-                pair_src.push_back(upd_k[u]);
-                tgt_pair_ptr.back()++;
-            }
-        }
-        h_tgt_ptr[n_steps] = (int)tgt_tile.size();
-        const double t3 = (double)TS * TS * TS;
-        chol_flops = t3 / 3.0 * NT + t3 * (double)col_rows.size() + 2.0 * t3 * (double)upd_i.size();
-    }
-    // trsm items per step
-    std::vector<int> h_trsm_ptr(n_steps + 1, 0), st_tile, st_col;
-    for (int st = 0; st < n_steps; ++st) {
-        h_trsm_ptr[st] = (int)st_tile.size();
-        for (int q = h_step_ptr[st]; q < h_step_ptr[st + 1]; ++q) {
-            const int c = step_col[q];
-            for (int w = h_col_ptr[c]; w < h_col_ptr[c + 1]; ++w) { st_tile.push_back(trsm_tile[w]); st_col.push_back(c); }
-        }
-    }
-    h_trsm_ptr[n_steps] = (int)st_tile.size();
-    if (getenv("SVI_DEBUG_PLAN")) {
-        for (int st = 0; st < n_steps; ++st) {
-            int mxpre = 0, mxpair = 0;
-            for (int q = h_step_ptr[st]; q < h_step_ptr[st + 1]; ++q) mxpre = std::max(mxpre, pre_ptr[step_col[q] + 1] - pre_ptr[step_col[q]]);
-            for (int t = h_tgt_ptr[st]; t < h_tgt_ptr[st + 1]; ++t) mxpair = std::max(mxpair, tgt_pair_ptr[t + 1] - tgt_pair_ptr[t]);
-            fprintf(stderr, "level %d: %d columns, max pre sources %d, %d update targets, max pairs per target %d, %d trsm tiles\n", st,
-                    h_step_ptr[st + 1] - h_step_ptr[st], mxpre, h_tgt_ptr[st + 1] - h_tgt_ptr[st], mxpair, h_trsm_ptr[st + 1] - h_trsm_ptr[st]);
-        }
-    }
-
-    SVI_TIMING_MARK(7);
-    // ---- Schur decomposition: always on 48 x 48 sub-tiles (8 poses x 8 poses), whatever TS is ----
-    // item  = (landmark, row chunk cX, column chunk cY): the poses of the landmark in either chunk as
-    //         8-bit masks plus the first lm-major edge of each segment
-    // job   = a run of items of ONE sub-tile, processed by one wavefront (lane = 6x6 block of the sub-tile)
-    constexpr int PBS = 8, SUB = 48;
-    const int Q = TS / SUB;          // sub-tiles per tile edge
-    const int NSUB = NT * Q;         // sub-tile rows of the padded system
-    // duplicate (pose, landmark) edges would alias one 6x6 block inside an item; the reference never
-    // creates them (one measurement per landmark per keyframe), reject instead of mis-summing
-    for (int l = 0; l < Ll; ++l)
-        for (int a = lm_ptr[l] + 1; a < lm_ptr[l + 1]; ++a)
-            if (e_pose[a] == e_pose[a - 1])
-                return fail(SVI_ERR_UNSUPPORTED, "two projection edges between pose %lld and landmark %lld",
-                            (long long)ba->poses[ba->pose_order[e_pose[a]]].id, (long long)ba->lms[ba->lm_order[L0 + l]].id);
-    // stored sub-tiles: every lower sub-tile inside a stored tile (they all have to be (re)written per trial)
-    std::vector<int> sub_map((size_t)NSUB * NSUB, -1), sub_cx, sub_cy, sub_tile;
-    for (int t = 0; t < n_tiles; ++t)
-        for (int sx = 0; sx < Q; ++sx)
-            for (int sy = 0; sy < Q; ++sy) {
-                const int cx = tile_ti[t] * Q + sx, cy = tile_tj[t] * Q + sy;
-                if (cy > cx) continue;
-                sub_map[(size_t)cx * NSUB + cy] = (int)sub_cx.size();
-                sub_cx.push_back(cx); sub_cy.push_back(cy); sub_tile.push_back(t);
-            }
-    const int n_sub = (int)sub_cx.size();
-    // Schur work list.  A stored 48 x 48 sub-tile is four CELLS of 4 x 4 poses (24 x 24); an item is one landmark in one
-    // cell: its edges to the cell's row poses and to its column poses (masks over the four poses of each).  Cells of
-    // four poses instead of eight raise the share of (pose, pose) lanes that have work from 36 % to 61 % at KITTI-like
-    // co-visibility.  A quarter job is a run of <= L items of one cell, a wavefront job four quarter jobs of similar
-    // length (one per group of 16 lanes), so that the four quarters of a wave finish together.
-    constexpr int PQ = 4;
-    struct Item { int cell, lm, a0, b0, masks; };
-    std::vector<Item> items;
-    items.reserve((size_t)E * 2);
-    struct Seg { int chunk, begin, mask, count; };
-    std::vector<Seg> seg;
-    int64_t total_pairs = 0;
-    for (int l = 0; l < Ll; ++l) {
-        if (lm_fixed[l]) continue;
-        int a = lm_ptr[l];
-        const int end = lm_ptr[l + 1];
-        while (a < end && pose_red[e_pose[a]] < 0) ++a; // edges to fixed poses come first
-        seg.clear();
-        while (a < end) {
-            const int c = pose_red[e_pose[a]] / PQ;
-            Seg sg{c, a, 0, 0};
-            while (a < end && pose_red[e_pose[a]] / PQ == c) { sg.mask |= 1 << (pose_red[e_pose[a]] % PQ); ++sg.count; ++a; }
-            seg.push_back(sg);
-        }
-        for (size_t x = 0; x < seg.size(); ++x)
-            for (size_t y = 0; y <= x; ++y) {
-                const int qx = seg[x].chunk, qy = seg[y].chunk; // qx >= qy: edges of a landmark ascend in reduced index
-                if (qy > qx) return fail(SVI_ERR_STATE, "internal: landmark edges not in reduced pose order");
-                const int sub = sub_map[(size_t)(qx / 2) * NSUB + qy / 2];
-                if (sub < 0) return fail(SVI_ERR_STATE, "internal: Schur sub-tile outside the tile structure");
-                items.push_back({4 * sub + 2 * (qx % 2) + (qy % 2), l, seg[x].begin, seg[y].begin, seg[x].mask | (seg[y].mask << 8)});
-                total_pairs += (x == y) ? (int64_t)seg[x].count * (seg[x].count + 1) / 2 : (int64_t)seg[x].count * seg[y].count;
-            }
-    }
-    { // stable counting sort by cell
-        std::vector<int> cnt(4 * n_sub + 1, 0);
-        std::vector<Item> out(items.size());
-        for (const Item& it : items) cnt[it.cell + 1]++;
-        for (int c = 0; c < 4 * n_sub; ++c) cnt[c + 1] += cnt[c];
-        for (const Item& it : items) out[cnt[it.cell]++] = it;
-        items.swap(out);
-    }
-    const int n_items = (int)items.size();
-    std::vector<int> it_pack((size_t)4 * std::max(n_items, 1));
-    for (int i = 0; i < n_items; ++i) {
-        it_pack[4 * i] = items[i].lm; it_pack[4 * i + 1] = items[i].a0; it_pack[4 * i + 2] = items[i].b0; it_pack[4 * i + 3] = items[i].masks;
-    }
-    // quarter jobs: as many as fit on the chip at once - the kernel holds two waves per SIMD (214 VGPRs, 59 KB of LDS
-    // per workgroup), one more would wait for a whole round.  Measured at config 4 with the current kernels (quarter
-    // jobs: Schur + assemble us): 4096: 207 + 22, 6144: 185 + 27, 8192: 176 + 33, 10240: 209 + 38.
-    const int n_cells = 4 * n_sub;
-    int n_cu = 256;
-    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ba->opt.device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
-    const int64_t qj_cap = (int64_t)4 * (n_cu * 4 * 2);
-    std::vector<int> cell_count;
-    for (int i = 0; i < n_items;) { int j = i; while (j < n_items && items[j].cell == items[i].cell) ++j; cell_count.push_back(j - i); i = j; }
-    auto pieces = [&](int len) { int64_t n = 0; for (int c : cell_count) n += (c + len - 1) / len; return n; };
-    int L = 16;
-    while (L < 1024 && pieces(L) > qj_cap) ++L;
-    struct QJob { int begin, end, cell; };
-    std::vector<QJob> qjobs;
-    for (int i = 0; i < n_items;) {
-        const int cell = items[i].cell;
-        int j = i;
-        while (j < n_items && items[j].cell == cell && j - i < L) ++j;
-        qjobs.push_back({i, j, cell});
-        i = j;
-    }
-    // waves take four quarter jobs of similar length; the slabs of a cell are summed in the order of its pieces
-    std::vector<int> qorder(qjobs.size());
-    for (size_t i = 0; i < qorder.size(); ++i) qorder[i] = (int)i;
-    std::stable_sort(qorder.begin(), qorder.end(), [&](int a, int b) { return qjobs[a].end - qjobs[a].begin > qjobs[b].end - qjobs[b].begin; });
-    const int n_jobs = ((int)qjobs.size() + 3) / 4;
-    std::vector<int> qj_begin((size_t)4 * std::max(n_jobs, 1), 0), qj_end((size_t)4 * std::max(n_jobs, 1), 0), qj_diag((size_t)4 * std::max(n_jobs, 1), 0);
-    std::vector<int> job_len(std::max(n_jobs, 1), 0), slot_of(qjobs.size(), -1);
-    for (size_t k = 0; k < qorder.size(); ++k) {
-        const QJob& q = qjobs[qorder[k]];
-        qj_begin[k] = q.begin; qj_end[k] = q.end;
-        const int sub = q.cell / 4, u = (q.cell / 2) % 2, v = q.cell % 2;
-        qj_diag[k] = (sub_cx[sub] == sub_cy[sub] && u == v) ? 1 : 0;
-        job_len[k / 4] = std::max(job_len[k / 4], q.end - q.begin);
-        slot_of[qorder[k]] = (int)k;
-    }
-    std::vector<int> cell_qj_ptr(n_cells + 1, 0), cell_qj;
-    {
-        size_t k = 0;
-        for (int c = 0; c < n_cells; ++c) {
-            cell_qj_ptr[c] = (int)cell_qj.size();
-            while (k < qjobs.size() && qjobs[k].cell == c) { cell_qj.push_back(slot_of[k]); ++k; } // qjobs ascend in cell
-        }
-        cell_qj_ptr[n_cells] = (int)cell_qj.size();
-    }
-    std::vector<std::vector<int>> taux(n_sub);
-    for (int k = 0; k < (int)se3_i.size(); ++k) {
-        const int ri = pose_red[se3_i[k]], rj = pose_red[se3_j[k]];
-        if (ri < 0 || rj < 0 || ri == rj) continue;
-        const int tr = ri > rj ? 0 : 1; // row pose = the one with the larger reduced index
-        const int hi = std::max(ri, rj), lo = std::min(ri, rj);
-        const int sub = sub_map[(size_t)(hi / PBS) * NSUB + lo / PBS];
-        if (sub < 0) return fail(SVI_ERR_STATE, "internal: odometry block outside the tile structure");
-        taux[sub].push_back((k << 1) | tr);
-    }
-    std::vector<int> sub_aux_ptr(n_sub + 1, 0), sub_aux_ref;
-    for (int t = 0; t < n_sub; ++t) {
-        sub_aux_ptr[t] = (int)sub_aux_ref.size();
-        sub_aux_ref.insert(sub_aux_ref.end(), taux[t].begin(), taux[t].end());
-    }
-    sub_aux_ptr[n_sub] = (int)sub_aux_ref.size();
-
-    SVI_TIMING_MARK(8);
-    // ---- upload ----
-    d.Pn = Pn; d.Pf = Pf; d.Ll = Ll; d.E = E;
-    d.n_lm_blocks = n_lm_blocks; d.n_chunks = n_chunks;
-    d.n_se3 = (int)se3_i.size(); d.n_accel = (int)acc_pose.size(); d.n_lmlm = (int)ll_free.size();
-    d.info_planes = planes;
-    std::vector<double> hp((size_t)12 * Pn), hl((size_t)3 * Ll);
-    for (int s = 0; s < Pn; ++s) memcpy(&hp[(size_t)12 * s], ba->poses[ba->pose_order[s]].T, 96);
-    for (int l = 0; l < Ll; ++l) memcpy(&hl[(size_t)3 * l], ba->lms[ba->lm_order[L0 + l]].p, 24);
-    for (int b = 0; b < 2; ++b) {
-        const double* p = nullptr;
-        SVI_TRY(dev_upload(ba, hp, &p)); d.pose[b] = const_cast<double*>(p);
-        SVI_TRY(dev_upload(ba, hl, &p)); d.lm[b] = const_cast<double*>(p);
-    }
-    SVI_TRY(dev_upload(ba, pose_red, &d.pose_red));
-    SVI_TRY(dev_upload(ba, lm_fixed, &d.lm_fixed));
-    SVI_TRY(dev_upload(ba, e_pose, &d.e_pose));
-    SVI_TRY(dev_upload(ba, e_lm, &d.e_lm));
-    SVI_TRY(dev_upload(ba, e_flags, &d.e_flags));
-    SVI_TRY(dev_upload(ba, e_zi, &d.e_zi));
-    SVI_TRY(dev_upload(ba, lm_ptr, &d.lm_ptr));
-    SVI_TRY(dev_upload(ba, lb_lm, &d.lb_lm));
-    SVI_TRY(dev_upload(ba, pm_lm, &d.pm_lm));
-    SVI_TRY(dev_upload(ba, pm_flags, &d.pm_flags));
-    SVI_TRY(dev_upload(ba, pm_zi, &d.pm_zi));
-    SVI_TRY(dev_upload(ba, chunk_pose, &d.chunk_pose));
-    SVI_TRY(dev_upload(ba, chunk_begin, &d.chunk_begin));
-    SVI_TRY(dev_upload(ba, pose_chunk_ptr, &d.pose_chunk_ptr));
-    SVI_TRY(dev_upload(ba, se3_i, &d.se3_i));
-    SVI_TRY(dev_upload(ba, se3_j, &d.se3_j));
-    SVI_TRY(dev_upload(ba, se3_Z, &d.se3_Z));
-    SVI_TRY(dev_upload(ba, se3_info, &d.se3_info));
-    SVI_TRY(dev_upload(ba, se3_robust, &d.se3_robust));
-    SVI_TRY(dev_upload(ba, acc_pose, &d.acc_pose));
-    SVI_TRY(dev_upload(ba, acc_a, &d.acc_a));
-    SVI_TRY(dev_upload(ba, acc_info, &d.acc_info));
-    SVI_TRY(dev_upload(ba, ll_free, &d.ll_free));
-    SVI_TRY(dev_upload(ba, ll_ref, &d.ll_ref));
-    SVI_TRY(dev_upload(ba, ll_z, &d.ll_z));
-    SVI_TRY(dev_upload(ba, ll_info, &d.ll_info));
-    SVI_TRY(dev_upload(ba, ll_robust, &d.ll_robust));
-    SVI_TRY(dev_upload(ba, lm_ll_ptr, &d.lm_ll_ptr));
-    SVI_TRY(dev_upload(ba, pose_aux_ptr, &d.pose_aux_ptr));
-    SVI_TRY(dev_upload(ba, pose_aux_ref, &d.pose_aux_ref));
-    {
-        const int* p = nullptr;
-        SVI_TRY(dev_upload(ba, red_slot, &p)); ba->red_slot = const_cast<int*>(p);
-        SVI_TRY(dev_upload(ba, e_orig, &p)); ba->e_orig = const_cast<int*>(p);
-    }
-    SVI_TRY(dev_alloc(ba, (size_t)12 * E, &d.NZ));
-    SVI_TRY(dev_alloc(ba, (size_t)6 * Ll, &d.Hll));
-    SVI_TRY(dev_alloc(ba, (size_t)3 * Ll, &d.bl));
-    SVI_TRY(dev_alloc(ba, (size_t)6 * Ll, &d.Hinv));
-    SVI_TRY(dev_alloc(ba, (size_t)12 * std::max(Ll, 1), &d.HinvB));
-    SVI_TRY(dev_alloc(ba, (size_t)27 * n_chunks, &d.chunk_out));
-    SVI_TRY(dev_alloc(ba, (size_t)120 * d.n_se3, &d.se3_out));
-    SVI_TRY(dev_alloc(ba, (size_t)42 * d.n_accel, &d.acc_out));
-    d.lin_count = 27 * Pf + 2 + o.n_ranks;
-    SVI_TRY(dev_alloc(ba, (size_t)d.lin_count, &d.lin_buf));
-    d.Hpp = d.lin_buf; d.bp = d.lin_buf + (size_t)21 * Pf; d.lin_scal = d.lin_buf + (size_t)27 * Pf;
-    SVI_TRY(dev_alloc(ba, (size_t)16 * std::max(n_lm_blocks, 1), &d.block_part));
-    d.TS = TS; d.NT = NT; d.n_tiles = n_tiles;
-    SVI_TRY(dev_upload(ba, tile_map, &d.tile_map));
-    // [ g | tiles with contributions | fill-in tiles ]: the all-reduce payload is the prefix g + contributing tiles
-    d.red_count = NT * TS + n_tiles_orig * TS * TS;
-    SVI_TRY(dev_alloc(ba, 2 + (size_t)NT * TS + (size_t)n_tiles * TS * TS, &d.red_base)); // two doubles in front: see linearize()
-    d.g = d.red_base + 2;
-    d.S = d.g + (size_t)NT * TS;
-    SVI_TRY(dev_alloc(ba, (size_t)n_tiles * TS * TS, &d.Lt));
-    SVI_TRY(dev_alloc(ba, (size_t)NT * TS * TS, &d.Linv));
-    SVI_TRY(dev_alloc(ba, (size_t)NT * TS, &d.dx));
-    SVI_TRY(dev_alloc(ba, 1, &d.chol_status));
-    SVI_HIP(hipMemsetAsync(d.chol_status, 0, sizeof(int), ba->stream));
-    d.n_items = n_items; d.n_jobs = n_jobs; d.n_sub = n_sub;
-    SVI_TRY(dev_upload(ba, it_pack, &d.it_pack));
-    SVI_TRY(dev_upload(ba, qj_begin, &d.qj_begin));
-    SVI_TRY(dev_upload(ba, qj_end, &d.qj_end));
-    SVI_TRY(dev_upload(ba, qj_diag, &d.qj_diag));
-    SVI_TRY(dev_upload(ba, job_len, &d.job_len));
-    SVI_TRY(dev_alloc(ba, (size_t)std::max(n_jobs, 1) * 36 * 64, &d.slab, false));
-    SVI_TRY(dev_alloc(ba, (size_t)std::max(n_jobs, 1) * 4 * 6 * 4, &d.gslab, false));
-    SVI_TRY(dev_upload(ba, cell_qj_ptr, &d.cell_qj_ptr));
-    SVI_TRY(dev_upload(ba, cell_qj, &d.cell_qj));
-    SVI_TRY(dev_upload(ba, sub_cx, &d.sub_cx));
-    SVI_TRY(dev_upload(ba, sub_cy, &d.sub_cy));
-    SVI_TRY(dev_upload(ba, sub_tile, &d.sub_tile));
-    SVI_TRY(dev_upload(ba, sub_aux_ptr, &d.sub_aux_ptr));
-    SVI_TRY(dev_upload(ba, sub_aux_ref, &d.sub_aux_ref));
-    d.add_pose_terms = d.add_aux_blocks = (o.rank == 0) ? 1 : 0;
-    d.lin_from_red = 0;
-    SVI_TRY(dev_alloc(ba, 16, &d.scal));
-    d.aux_blocks = std::max(1, (std::max(d.n_se3, d.n_accel) + 63) / 64);
-    SVI_TRY(dev_alloc(ba, (size_t)2 * d.aux_blocks, &d.aux_part));
-    SVI_TRY(dev_alloc(ba, 1, &d.aux_count));
-    SVI_HIP(hipMemsetAsync(d.aux_count, 0, sizeof(int), ba->stream));
-    if (o.n_ranks > 1) SVI_TRY(dev_alloc(ba, (size_t)3 * Ltot, &ba->lm_all));
-
-    CholPlan& p = ba->plan;
-    p.TS = TS; p.NT = NT; p.n_steps = n_steps;
-    ba->h_step_ptr = h_step_ptr; ba->h_tgt_ptr = h_tgt_ptr; ba->h_trsm_ptr = h_trsm_ptr;
-    p.h_step_ptr = ba->h_step_ptr.data(); p.h_tgt_ptr = ba->h_tgt_ptr.data(); p.h_trsm_ptr = ba->h_trsm_ptr.data();
-    SVI_TRY(dev_upload(ba, h_col_ptr, &p.col_ptr));
-    SVI_TRY(dev_upload(ba, trsm_tile, &p.trsm_tile));
-    SVI_TRY(dev_upload(ba, trsm_row, &p.trsm_row));
-    SVI_TRY(dev_upload(ba, step_col, &p.step_col));
-    {
-        // everything a chain / back-substitution workgroup needs to know about its column in ONE record (two 16-byte
-        // loads side by side instead of a chain of three dependent index loads at the start of every launch)
-        std::vector<int> step_desc((size_t)8 * std::max<size_t>(step_col.size(), 1), 0);
-        for (size_t q = 0; q < step_col.size(); ++q) {
-            const int c = step_col[q];
-            int* r = &step_desc[8 * q];
-            r[0] = c; r[1] = diag_tile[c]; r[2] = pre_ptr[c]; r[3] = pre_ptr[c + 1] - pre_ptr[c];
-            r[4] = h_col_ptr[c]; r[5] = h_col_ptr[c + 1] - h_col_ptr[c];
-        }
-        SVI_TRY(dev_upload(ba, step_desc, &p.step_desc));
-    }
-    SVI_TRY(dev_upload(ba, diag_tile, &p.diag_tile));
-    SVI_TRY(dev_upload(ba, pre_ptr, &p.pre_ptr));
-    SVI_TRY(dev_upload(ba, pre_tile, &p.pre_tile));
-    SVI_TRY(dev_upload(ba, pre_col, &p.pre_col));
-    SVI_TRY(dev_upload(ba, tgt_tile, &p.tgt_tile));
-    SVI_TRY(dev_upload(ba, tgt_row, &p.tgt_row));
-    SVI_TRY(dev_upload(ba, tgt_pair_ptr, &p.tgt_pair_ptr));
-    SVI_TRY(dev_upload(ba, pair_a, &p.pair_a));
-    SVI_TRY(dev_upload(ba, pair_b, &p.pair_b));
-    SVI_TRY(dev_upload(ba, pair_src, &p.pair_src));
-    SVI_TRY(dev_upload(ba, st_tile, &p.st_tile));
-    SVI_TRY(dev_upload(ba, st_col, &p.st_col));
-
-    SVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&ba->h_scal), 16 * sizeof(double)));
-    SVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&ba->h_status), sizeof(int) * 4));
-    ba->h_status[0] = ba->h_status[1] = 0;
-    ba->pub_seq = 0;
-    ba_configure_kernels(TS);
-    SVI_HIP(hipStreamSynchronize(ba->stream));
-
-    svi_ba_stats& st = ba->stats;
-    const uint64_t it0 = st.lm_iterations, tr0 = st.lm_trials, cf0 = st.chol_failures;
-    st = svi_ba_stats{};
-    st.lm_iterations = it0; st.lm_trials = tr0; st.chol_failures = cf0;
-    st.n_poses = Pn; st.n_poses_free = Pf; st.n_landmarks = Ltot; st.n_landmarks_local = Ll;
-    st.n_edges_proj = Etot; st.n_edges_proj_local = E;
-    st.n_edges_se3 = (int64_t)ba->se3.size(); st.n_edges_accel = (int64_t)ba->acc.size(); st.n_edges_lmlm = (int64_t)ba->lmlm.size();
-    st.n_schur_tiles = n_jobs; st.n_window_blocks = total_pairs;
-    st.chol_n = n; st.chol_tile = TS; st.chol_tiles_nnz = n_tiles; st.chol_steps = n_steps;
-    st.reduce_doubles = d.red_count;
-    st.chol_flops = chol_flops;
-    SVI_TIMING_MARK(9);
     return SVI_OK;
 }
 
@@ -1126,15 +358,76 @@ int add_proj(svi_ba* ba, int type, int64_t pose_id, int64_t lm_id, const double*
     auto il = ba->lm_ix.find(lm_id);
     if (ip == ba->pose_ix.end()) return fail(SVI_ERR_NOT_FOUND, "pose id %lld not in graph", (long long)pose_id);
     if (il == ba->lm_ix.end()) return fail(SVI_ERR_NOT_FOUND, "landmark id %lld not in graph", (long long)lm_id);
-    HProj e{};
-    e.type = type; e.robust = robust ? 1 : 0; e.pose = ip->second; e.lm = il->second;
-    memcpy(e.z, z, 24); memcpy(e.info, info, 48);
-    ba->proj.push_back(e);
+    SVI_TRY(edges_push(ba, type, robust, ip->second, il->second, z, info));
     ba->initialized = false;
     return SVI_OK;
 }
 
 } // namespace
+
+// ---- the edge store -------------------------------------------------------------------------------------------------------
+int edges_push(svi_ba* ba, int type, int robust, int pose, int lm, const double* z, const double* info)
+{
+    EdgeStore& e = ba->proj;
+    const size_t i = e.size();
+    if (i == e.cap) { // the pinned array doubles; copies that may still read the old one are drained first
+        const size_t cap = std::max<size_t>(2 * e.cap, 4096);
+        double* nv = nullptr;
+        SVI_HIP(hipSetDevice(ba->opt.device));
+        SVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&nv), cap * 72));
+        if (e.vals) {
+            SVI_HIP(hipStreamSynchronize(ba->stream));
+            memcpy(nv, e.vals, i * 72);
+            (void)hipHostFree(e.vals);
+        }
+        e.vals = nv; e.cap = cap;
+    }
+    e.pose.push_back(pose); e.lm.push_back(lm);
+    e.flags.push_back((uint8_t)((type & 3) | (robust ? kFlagRobust : 0)));
+    memcpy(e.vals + 9 * i, z, 24);
+    memcpy(e.vals + 9 * i + 3, info, 48);
+    if (info[1] != 0.0 || info[2] != 0.0 || info[4] != 0.0) e.n_offdiag++;
+    ba->graph_version++;
+    return SVI_OK;
+}
+
+void edges_truncate(svi_ba* ba, size_t n)
+{
+    EdgeStore& e = ba->proj;
+    if (n >= e.size()) return;
+    for (size_t i = n; i < e.size(); ++i) { const double* f = e.info(i); if (f[1] != 0.0 || f[2] != 0.0 || f[4] != 0.0) e.n_offdiag--; }
+    e.pose.resize(n); e.lm.resize(n); e.flags.resize(n);
+    ba->raw_uploaded = std::min(ba->raw_uploaded, n);
+    ba->graph_version++;
+}
+
+// appends what has been added since the last flush to the device-side log (asynchronously, from pinned memory)
+int edges_flush(svi_ba* ba)
+{
+    EdgeStore& e = ba->proj;
+    const size_t E = e.size();
+    if (ba->raw_uploaded >= E) return SVI_OK;
+    SVI_HIP(hipSetDevice(ba->opt.device));
+    if (E > ba->raw_cap) { // grow the device log: new buffers, the uploaded part moves device to device
+        const size_t cap = std::max<size_t>({2 * ba->raw_cap, E, (size_t)4096});
+        DevBuf nl, nf;
+        SVI_TRY(nl.reserve(cap * 72));
+        SVI_TRY(nf.reserve(cap));
+        if (ba->raw_uploaded) {
+            SVI_HIP(hipMemcpyAsync(nl.p, ba->raw_log.p, ba->raw_uploaded * 72, hipMemcpyDeviceToDevice, ba->stream));
+            SVI_HIP(hipMemcpyAsync(nf.p, ba->raw_flags.p, ba->raw_uploaded, hipMemcpyDeviceToDevice, ba->stream));
+            SVI_HIP(hipStreamSynchronize(ba->stream));
+        }
+        ba->raw_log.release(); ba->raw_flags.release();
+        ba->raw_log = nl; ba->raw_flags = nf;
+        ba->raw_cap = cap;
+    }
+    const size_t first = ba->raw_uploaded, cnt = E - first;
+    SVI_HIP(hipMemcpyAsync(ba->raw_log.as<double>() + 9 * first, e.vals + 9 * first, cnt * 72, hipMemcpyHostToDevice, ba->stream));
+    SVI_HIP(hipMemcpyAsync(ba->raw_flags.as<uint8_t>() + first, e.flags.data() + first, cnt, hipMemcpyHostToDevice, ba->stream));
+    ba->raw_uploaded = E;
+    return SVI_OK;
+}
 
 // ---------------------------------------------------------------------------------------------
 // C ABI
@@ -1182,6 +475,7 @@ int svi_ba_destroy(svi_ba* ba)
     (void)hipSetDevice(ba->opt.device);
     (void)hipStreamSynchronize(ba->stream);
     free_device(ba);
+    if (ba->proj.vals) { (void)hipHostFree(ba->proj.vals); ba->proj.vals = nullptr; }
     ba->timer.release();
     ba->sweep_timer.release();
     if (ba->own_stream) (void)hipStreamDestroy(ba->stream);
@@ -1239,12 +533,13 @@ int svi_ba_add_edges_bulk(svi_ba* ba, int64_t n, const int32_t* type, const int6
     if (n == 0) return SVI_OK;
     if (!type || !pose_id || !lm_id || !z || !info) return fail(SVI_ERR_INVALID, "null argument");
     const size_t before = ba->proj.size();
+    ba->proj.pose.reserve(before + (size_t)n); ba->proj.lm.reserve(before + (size_t)n); ba->proj.flags.reserve(before + (size_t)n);
     for (int64_t i = 0; i < n; ++i) {
-        if (type[i] < 0 || type[i] > 2) { ba->proj.resize(before); return fail(SVI_ERR_INVALID, "edge %lld: unknown type %d", (long long)i, type[i]); }
+        if (type[i] < 0 || type[i] > 2) { edges_truncate(ba, before); return fail(SVI_ERR_INVALID, "edge %lld: unknown type %d", (long long)i, type[i]); }
         const int rc = add_proj(ba, type[i], pose_id[i], lm_id[i], z + 3 * i, info + 6 * i, robust ? robust[i] : 1);
-        if (rc != SVI_OK) { ba->proj.resize(before); return rc; }
+        if (rc != SVI_OK) { edges_truncate(ba, before); return rc; }
     }
-    return SVI_OK;
+    return edges_flush(ba);
 }
 
 int svi_ba_add_edge_se3(svi_ba* ba, int64_t id_i, int64_t id_j, const double Z[12], const double info[21], int robust)
@@ -1372,7 +667,7 @@ int svi_ba_add_measurements(svi_ba* ba, int64_t pose_id, int64_t n, const int64_
         }
     }
     if (stored) { stored[0] = cnt[0]; stored[1] = cnt[1]; stored[2] = cnt[2]; }
-    return SVI_OK;
+    return edges_flush(ba); // the new edges' values travel to the device-side log while the caller goes on building the graph
 }
 
 int svi_ba_initialize(svi_ba* ba)
@@ -1380,11 +675,15 @@ int svi_ba_initialize(svi_ba* ba)
     if (!ba) return fail(SVI_ERR_INVALID, "null handle");
     SVI_TRY(ensure_host(ba));
     if (int rc = use_device(ba->opt.device)) return rc;
-    free_device(ba);
+    SVI_HIP(hipStreamSynchronize(ba->stream)); // nothing may still read the buffers that are about to be refilled
     ba->cur = 0;
     ba->have_chi = false;
+    // every edit of the graph's structure clears `initialized`: if it is still set, the device structures are those of this very
+    // graph and only the estimates have to go back (g2o rebuilds everything per call; the result is the same)
+    if (ba->initialized) return reupload_state(ba);
+    invalidate_device(ba);
     const int rc = build_structure(ba);
-    if (rc != SVI_OK) { free_device(ba); return rc; }
+    if (rc != SVI_OK) { invalidate_device(ba); return rc; }
     ba->initialized = true;
     return SVI_OK;
 }
@@ -1516,10 +815,23 @@ int svi_ba_prune_diverged(svi_ba* ba, int64_t* removed)
         ba->lm_ix.clear();
         for (int i = 0; i < nl; ++i) if (remap[i] >= 0) { ba->lm_ix[ba->lms[i].id] = (int)keep.size(); keep.push_back(ba->lms[i]); }
         ba->lms.swap(keep);
-        std::vector<HProj> pe;
-        pe.reserve(ba->proj.size());
-        for (HProj e : ba->proj) if (remap[e.lm] >= 0) { e.lm = remap[e.lm]; pe.push_back(e); }
-        ba->proj.swap(pe);
+        {   // compact the edge store in place (the device-side log is in insertion order: refilled by the next flush)
+            EdgeStore& e = ba->proj;
+            SVI_HIP(hipStreamSynchronize(ba->stream)); // an upload may still read the pinned values
+            size_t w = 0;
+            e.n_offdiag = 0;
+            for (size_t i = 0; i < e.size(); ++i) {
+                if (remap[e.lm[i]] < 0) continue;
+                e.pose[w] = e.pose[i]; e.lm[w] = remap[e.lm[i]]; e.flags[w] = e.flags[i];
+                if (w != i) memmove(e.vals + 9 * w, e.vals + 9 * i, 72);
+                const double* f = e.info(w);
+                if (f[1] != 0.0 || f[2] != 0.0 || f[4] != 0.0) e.n_offdiag++;
+                ++w;
+            }
+            e.pose.resize(w); e.lm.resize(w); e.flags.resize(w);
+            ba->raw_uploaded = 0;
+        }
+        ba->graph_version++;
         std::vector<HLL> le;
         for (HLL e : ba->lmlm) if (remap[e.i] >= 0 && remap[e.j] >= 0) { e.i = remap[e.i]; e.j = remap[e.j]; le.push_back(e); }
         ba->lmlm.swap(le);

@@ -14,7 +14,21 @@ namespace svi {
 
 struct HPose { int64_t id; double T[12]; int fixed; };
 struct HLm   { int64_t id; double p[3]; int fixed; };
-struct HProj { int type, robust, pose, lm; double z[3]; double info[6]; };
+// Projection edges as they were added (insertion order), structure of arrays: the keys stay in ordinary vectors (the
+// structure analysis sorts them), the values (z 3, upper triangle of the information 6: 72 bytes) sit in PINNED host memory
+// and are appended to a device-side log as they arrive - an initialize() never touches them again (ba_structure.cpp).
+struct EdgeStore {
+    std::vector<int> pose, lm;          // indices into svi_ba::poses / lms
+    std::vector<uint8_t> flags;         // (type & 3) | kFlagRobust
+    double* vals = nullptr;             // pinned, 9 doubles per edge
+    size_t  cap = 0;                    // edges the pinned array has room for
+    size_t  n_offdiag = 0;              // edges whose information has off-diagonal entries
+    size_t size() const { return pose.size(); }
+    const double* z(size_t i) const { return vals + 9 * i; }
+    const double* info(size_t i) const { return vals + 9 * i + 3; }
+    int type(size_t i) const { return flags[i] & 3; }
+    bool robust(size_t i) const { return (flags[i] & 4u) != 0; }
+};
 struct HSe3  { int i, j, robust; double Z[12]; double info[21]; };
 struct HAcc  { int pose; double a[3]; double off[12]; double info[6]; };
 struct HLL   { int i, j, robust; double z[3]; double info[6]; };
@@ -39,7 +53,7 @@ struct svi_ba {
     // ---- graph (host) ----
     std::vector<svi::HPose> poses;
     std::vector<svi::HLm>   lms;
-    std::vector<svi::HProj> proj;
+    svi::EdgeStore proj;
     std::vector<svi::HSe3>  se3;
     std::vector<svi::HAcc>  acc;
     std::vector<svi::HLL>   lmlm;
@@ -56,7 +70,12 @@ struct svi_ba {
     svi::BaDev d{};
     svi::CholPlan plan{};
     int cur = 0;
-    std::vector<void*> allocs;      // everything hipMalloc'ed by initialize()
+    std::vector<svi::DevBuf> pool;  // the device buffers of initialize(), in allocation order; kept (and grown) across calls
+    svi::DevBuf raw_log, raw_flags; // projection-edge values (72 B) and flags in INSERTION order on the device, appended to
+    size_t raw_cap = 0;             // edges the device log has room for
+    size_t raw_uploaded = 0;        // edges of `proj` already in the log
+    uint64_t graph_version = 0;     // bumped by every edit of the graph's STRUCTURE (vertices, edges, fixed flags)
+    uint64_t built_version = ~0ull; // graph_version the device structures were built for
     double* h_scal = nullptr;       // pinned readback (16 doubles)
     int*    h_status = nullptr;     // pinned: [0] factorisation status, [1] sequence number of the last published results
     int     pub_seq = 0;
@@ -86,3 +105,7 @@ struct svi_ba {
 
 // host copy of the estimates in step with the device (ba_host.cpp); collective with several ranks when it has to act
 int ensure_host(svi_ba* ba);
+// edge store (ba_host.cpp): append one edge / drop everything from `n` on / bring the device-side log up to date
+int edges_push(svi_ba* ba, int type, int robust, int pose, int lm, const double* z, const double* info);
+void edges_truncate(svi_ba* ba, size_t n);
+int edges_flush(svi_ba* ba);

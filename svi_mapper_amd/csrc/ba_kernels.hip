@@ -1388,6 +1388,37 @@ void ba_debug_aux_jacobians(const BaDev& d, int cur, double* se3_err, double* se
     hipLaunchKernelGGL(k_debug_aux_jacobians, dim3(d.aux_blocks), dim3(kAuxThreads), 0, S_(st), d, cur, se3_err, se3_Ji, se3_Jj, acc_err, acc_J);
 }
 
+// Edge values from the device-side log (insertion order, 9 doubles per edge: z, upper triangle of the information) into the
+// double2 planes the sweeps read: out[2 * ((v / 2) * stride + k) + (v & 1)], v = 0..2 z, 3.. information (diagonal only when
+// planes == 3).  k-th output edge = log row src[via ? via[k] : k]; lm_out (nullable) = lm_in[via[k]] for the pose-major copy.
+__global__ __launch_bounds__(256) void k_gather_edges(const double* __restrict__ raw, const uint8_t* __restrict__ raw_flags, const int* __restrict__ src,
+                                                      const int* __restrict__ via, int count, int stride, int planes, double* __restrict__ out_zi,
+                                                      uint8_t* __restrict__ out_flags, const int* __restrict__ lm_in, int* __restrict__ lm_out)
+{
+    const int k = blockIdx.x * 256 + threadIdx.x;
+    if (k >= count) return;
+    const int m = via ? via[k] : k;
+    const int s = src[m];
+    const double* r = raw + (size_t)9 * s;
+    double v[10];
+    v[0] = r[0]; v[1] = r[1]; v[2] = r[2];
+    if (planes == 3) { v[3] = r[3]; v[4] = r[6]; v[5] = r[8]; v[6] = 0.0; v[7] = 0.0; v[8] = 0.0; v[9] = 0.0; }
+    else { for (int q = 0; q < 6; ++q) v[3 + q] = r[3 + q]; v[9] = 0.0; }
+    const int np2 = (3 + planes + 1) / 2;
+    double2* out = reinterpret_cast<double2*>(out_zi);
+    for (int p = 0; p < np2; ++p) out[(size_t)p * stride + k] = make_double2(v[2 * p], v[2 * p + 1]);
+    out_flags[k] = raw_flags[s];
+    if (lm_out) lm_out[k] = lm_in[m];
+}
+
+void ba_gather_edges(const double* raw, const uint8_t* raw_flags, const int* src, const int* via, int count, int stride, int planes, double* out_zi,
+                     uint8_t* out_flags, const int* lm_in, int* lm_out, void* st)
+{
+    if (count > 0)
+        hipLaunchKernelGGL(k_gather_edges, dim3((count + 255) / 256), dim3(256), 0, S_(st), raw, raw_flags, src, via, count, stride, planes, out_zi,
+                           out_flags, lm_in, lm_out);
+}
+
 void ba_configure_kernels(int) {}
 
 } // namespace svi

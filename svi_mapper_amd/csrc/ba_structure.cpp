@@ -1,0 +1,1015 @@
+// ba_structure.cpp — svi_ba_initialize: the structure analysis behind g2o's initializeOptimization + buildStructure
+// (Cg2oOptimizer.cpp:957 runs it at the top of EVERY optimize() call, so it is part of what one call costs).
+//
+// Pieces, in order (each a function below, sharing one Build context):
+//   order_vertices      ascending id = g2o's index mapping; reduced (free) poses
+//   sort_edges          projection edges by (landmark, pose): one counting sort over compact keys -> CSR per landmark
+//   elimination_order   nested dissection of the key-frame sequence, candidates evaluated symbolically at tile level
+//   local_edges         this rank's landmark range, lm-major order (landmark, elimination index), pose-major copy
+//   aux_edges           odometry / gravity / landmark-closure edges
+//   tile_structure      tiles of the reduced system, symbolic fill, dependency levels, grouped updates
+//   schur_work_lists    cells, items, quarter jobs, slabs
+//   upload              device buffers (kept across calls, re-allocated only when they grow)
+//
+// What keeps it short of the LM loop's own time (config 4: 800 k edges, 100 k landmarks):
+//   * no per-landmark containers: every per-landmark list is a range of the sorted edge array;
+//   * the edge VALUES (z, information: 72 bytes per edge) never pass through the host again: they live in a device-side
+//     log in insertion order, only the edges added since the last call are uploaded (through pinned staging), and two
+//     gather kernels lay them out lm-major and pose-major from the permutations computed here;
+//   * device buffers are re-used between calls; the big loops run on a few threads.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <functional>
+#include <numeric>
+#include <thread>
+
+#include "ba_host.h"
+#include "ba_math.h"
+
+namespace svi {
+void ba_gather_edges(const double* raw, const uint8_t* raw_flags, const int* src, const int* via, int count, int stride, int planes, double* out_zi,
+                     uint8_t* out_flags, const int* lm_in, int* lm_out, void* st);
+void ba_configure_kernels(int TS);
+}
+
+using namespace svi;
+
+namespace {
+
+#define SVI_TRY(x) do { int rc_ = (x); if (rc_ != SVI_OK) return rc_; } while (0)
+
+// f(begin, end) over contiguous chunks of [0, n) on up to 8 threads (the caller's thread takes the first chunk)
+template <class F> void parallel_chunks(size_t n, size_t min_chunk, F&& f)
+{
+    unsigned hw = std::thread::hardware_concurrency();
+    size_t nt = std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)8, std::max<size_t>(n / std::max<size_t>(min_chunk, 1), 1)});
+    if (nt <= 1) { f((size_t)0, n); return; }
+    std::vector<std::thread> th;
+    const size_t per = (n + nt - 1) / nt;
+    for (size_t t = 1; t < nt; ++t) {
+        const size_t a = std::min(n, t * per), b = std::min(n, (t + 1) * per);
+        if (a < b) th.emplace_back([&f, a, b]() { f(a, b); });
+    }
+    f((size_t)0, std::min(n, per));
+    for (auto& x : th) x.join();
+}
+
+struct Build {
+    svi_ba* ba;
+    bool dbg;
+    std::chrono::steady_clock::time_point t0;
+    int Pn = 0, Pf = 0, Ltot = 0;
+    int64_t Etot = 0;
+    std::vector<int> pose_slot, pose_red, red_slot, lm_slot;
+    // all projection edges sorted by (landmark slot, pose slot, insertion): insertion index and pose slot, CSR per landmark slot
+    std::vector<int> g_edge, g_pose, g_ptr;
+    // which free poses share a landmark: lower triangle over NATURAL reduced indices (only for Pf <= 4096: 16 MB), longest track
+    std::vector<uint8_t> cpl;
+    bool use_cpl = false;
+    int span = 0;
+    // this rank
+    int L0 = 0, Ll = 0, E = 0, Epm = 0;
+    std::vector<int> loc, e_pose, e_lm, lm_ptr, lb_lm, pm, pm_src, chunk_pose, chunk_begin, pose_chunk_ptr;
+    std::vector<uint8_t> lm_fixed;
+    int n_lm_blocks = 0, n_chunks = 0, planes = 3;
+    // aux
+    std::vector<int> se3_i, se3_j, acc_pose, ll_free, lm_ll_ptr, pose_aux_ptr, pose_aux_ref;
+    std::vector<double> se3_Z, se3_info, acc_a, acc_info, ll_ref, ll_z, ll_info;
+    std::vector<uint8_t> se3_robust, ll_robust;
+    // tiles
+    int TS = 96, PB = 16, n = 0, NT = 0, n_tiles = 0, n_tiles_orig = 0, n_steps = 0;
+    std::vector<int> tile_map, tile_ti, tile_tj, h_col_ptr, trsm_tile, trsm_row, diag_tile, level, h_step_ptr, step_col, pre_ptr, pre_tile, pre_col,
+        h_tgt_ptr, tgt_tile, tgt_row, tgt_pair_ptr, pair_a, pair_b, pair_src, h_trsm_ptr, st_tile, st_col;
+    double chol_flops = 0.0;
+    // Schur
+    int n_sub = 0, n_items = 0, n_jobs = 0;
+    int64_t total_pairs = 0;
+    std::vector<int> sub_cx, sub_cy, sub_tile, it_pack, qj_begin, qj_end, qj_diag, job_len, cell_qj_ptr, cell_qj, sub_aux_ptr, sub_aux_ref;
+
+    void mark(int k) const
+    {
+        if (dbg) fprintf(stderr, "build_structure: section %d starts at %.2f ms\n", k, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+    }
+};
+
+// ---- device buffers that survive re-initialisation ----------------------------------------------------------------------
+struct Uploader {
+    svi_ba* ba;
+    size_t next = 0;
+    DevBuf& slot()
+    {
+        if (next == ba->pool.size()) ba->pool.emplace_back();
+        return ba->pool[next++];
+    }
+    template <class T> int up(const std::vector<T>& h, const T** out, size_t min_elems = 1)
+    {
+        DevBuf& b = slot();
+        const size_t cnt = std::max(h.size(), min_elems);
+        SVI_TRY(b.reserve(cnt * sizeof(T)));
+        if (!h.empty()) SVI_HIP(hipMemcpyAsync(b.p, h.data(), h.size() * sizeof(T), hipMemcpyHostToDevice, ba->stream));
+        *out = b.as<T>();
+        return SVI_OK;
+    }
+    template <class T> int alloc(size_t cnt, T** out, bool zero = true)
+    {
+        DevBuf& b = slot();
+        cnt = std::max<size_t>(cnt, 1);
+        SVI_TRY(b.reserve(cnt * sizeof(T)));
+        if (zero) SVI_HIP(hipMemsetAsync(b.p, 0, cnt * sizeof(T), ba->stream));
+        *out = b.as<T>();
+        return SVI_OK;
+    }
+};
+
+// ---- vertex order: ascending id (g2o index mapping) ---------------------------------------------------------------------
+void order_vertices(Build& b)
+{
+    svi_ba* ba = b.ba;
+    b.Pn = (int)ba->poses.size();
+    b.Ltot = (int)ba->lms.size();
+    ba->pose_order.resize(b.Pn);
+    std::iota(ba->pose_order.begin(), ba->pose_order.end(), 0);
+    std::sort(ba->pose_order.begin(), ba->pose_order.end(), [&](int x, int y) { return ba->poses[x].id < ba->poses[y].id; });
+    b.pose_slot.resize(b.Pn);
+    b.pose_red.resize(b.Pn);
+    b.red_slot.clear();
+    for (int s = 0; s < b.Pn; ++s) b.pose_slot[ba->pose_order[s]] = s;
+    for (int s = 0; s < b.Pn; ++s) {
+        if (ba->poses[ba->pose_order[s]].fixed) b.pose_red[s] = -1;
+        else { b.pose_red[s] = (int)b.red_slot.size(); b.red_slot.push_back(s); }
+    }
+    b.Pf = (int)b.red_slot.size();
+    ba->lm_order.resize(b.Ltot);
+    std::iota(ba->lm_order.begin(), ba->lm_order.end(), 0);
+    bool sorted = true; // landmarks usually arrive in ascending id (the reference adds them as they are created)
+    for (int i = 1; i < b.Ltot && sorted; ++i) sorted = ba->lms[i - 1].id < ba->lms[i].id;
+    if (!sorted) std::sort(ba->lm_order.begin(), ba->lm_order.end(), [&](int x, int y) { return ba->lms[x].id < ba->lms[y].id; });
+    b.lm_slot.resize(b.Ltot);
+    for (int s = 0; s < b.Ltot; ++s) b.lm_slot[ba->lm_order[s]] = s;
+}
+
+// ---- all projection edges by (landmark slot, pose slot, insertion order) ------------------------------------------------
+void sort_edges(Build& b)
+{
+    svi_ba* ba = b.ba;
+    const size_t E = ba->proj.size();
+    b.Etot = (int64_t)E;
+    std::vector<int> ls(E), ps(E);
+    parallel_chunks(E, 1 << 16, [&](size_t a, size_t z) {
+        for (size_t i = a; i < z; ++i) { ls[i] = b.lm_slot[ba->proj.lm[i]]; ps[i] = b.pose_slot[ba->proj.pose[i]]; }
+    });
+    b.planes = ba->proj.n_offdiag == 0 ? 3 : 6;
+    b.g_ptr.assign((size_t)b.Ltot + 1, 0);
+    for (size_t i = 0; i < E; ++i) b.g_ptr[ls[i] + 1]++;
+    for (int l = 0; l < b.Ltot; ++l) b.g_ptr[l + 1] += b.g_ptr[l];
+    b.g_edge.resize(E);
+    b.g_pose.resize(E);
+    {
+        std::vector<int> cur(b.g_ptr.begin(), b.g_ptr.end() - 1);
+        for (size_t i = 0; i < E; ++i) { const int k = cur[ls[i]]++; b.g_edge[k] = (int)i; b.g_pose[k] = ps[i]; }
+    }
+    // inside a landmark: by pose slot, ties in insertion order (the segments are short and nearly always sorted already)
+    parallel_chunks((size_t)b.Ltot, 1 << 13, [&](size_t la, size_t lz) {
+        for (size_t l = la; l < lz; ++l)
+            for (int i = b.g_ptr[l] + 1; i < b.g_ptr[l + 1]; ++i) {
+                const int p = b.g_pose[i], e = b.g_edge[i];
+                int j = i - 1;
+                while (j >= b.g_ptr[l] && b.g_pose[j] > p) { b.g_pose[j + 1] = b.g_pose[j]; b.g_edge[j + 1] = b.g_edge[j]; --j; }
+                b.g_pose[j + 1] = p; b.g_edge[j + 1] = e;
+            }
+    });
+}
+
+// ---- co-visibility of the free poses, from the sorted edge ranges ----------------------------------------------------------
+void pose_coupling(Build& b)
+{
+    svi_ba* ba = b.ba;
+    const int Pf = b.Pf;
+    b.use_cpl = Pf <= 4096; // longer sequences walk the landmarks where the matrix would be read
+    b.cpl.assign(b.use_cpl ? (size_t)Pf * Pf : 0, 0);
+    b.span = 0;
+    std::vector<int> reds; // free poses of one landmark, ascending (pose slots ascend, so do natural reduced indices)
+    for (int l = 0; l < b.Ltot; ++l) {
+        if (ba->lms[ba->lm_order[l]].fixed) continue;
+        reds.clear();
+        for (int k = b.g_ptr[l]; k < b.g_ptr[l + 1]; ++k) { const int r = b.pose_red[b.g_pose[k]]; if (r >= 0) reds.push_back(r); }
+        if (reds.empty()) continue;
+        b.span = std::max(b.span, reds.back() - reds.front());
+        if (b.use_cpl)
+            for (size_t x = 0; x < reds.size(); ++x) {
+                uint8_t* row = &b.cpl[(size_t)reds[x] * Pf];
+                for (size_t y = 0; y <= x; ++y) row[reds[y]] = 1;
+            }
+    }
+}
+
+// ---- elimination order of the reduced camera system (nested dissection of the key-frame sequence) ----------------------
+// The reduced system of a trajectory is block-banded: in natural order its Cholesky is ONE chain of tile columns.  Cutting
+// the sequence at separators as wide as the co-visibility span gives independent chains that are factorised side by side
+// (ba_chol.hip processes all columns of one dependency level per launch).  Every piece is a whole number of tiles except
+// the top separator, which comes last and absorbs the remainder, so the identity padding stays at the end of the range.
+void elimination_order(Build& b)
+{
+    svi_ba* ba = b.ba;
+    const svi_ba_options& o = ba->opt;
+    const int Pf = b.Pf;
+    ba->red_perm.resize(Pf);
+    std::iota(ba->red_perm.begin(), ba->red_perm.end(), 0);
+    const int TSo = o.chol_tile > 0 ? o.chol_tile : 96;
+    const int PBo = TSo / 6;
+    const int NTo = PBo > 0 ? (Pf + PBo - 1) / PBo : 0;
+    if (!(o.chol_order == 0 && PBo > 0 && NTo >= 6)) return;
+    const bool use_cpl = b.use_cpl;
+    const std::vector<uint8_t>& cpl = b.cpl;
+    int span = b.span;
+    std::vector<std::pair<int, int>> pp;
+    for (const HSe3& e : ba->se3) {
+        const int ri = b.pose_red[b.pose_slot[e.i]], rj = b.pose_red[b.pose_slot[e.j]];
+        if (ri >= 0 && rj >= 0) { pp.push_back({ri, rj}); span = std::max(span, std::abs(ri - rj)); }
+    }
+    const int rem = Pf % PBo;
+    // elimination order for separators of `w` tiles; false if the sequence is too short for it
+    auto make_perm = [&](int w, std::vector<int>& perm) {
+        const int sep = w * PBo;
+        const int sep_top = rem == 0 ? sep : rem + PBo * ((std::max(sep - rem, 0) + PBo - 1) / PBo); // absorbs the remainder
+        if (Pf < sep_top + 4 * PBo) return false;
+        std::vector<std::pair<int, int>> pieces; // natural ranges in elimination order
+        std::function<void(int, int, int)> rec = [&](int a, int z, int wd) {
+            const int len = z - a;
+            if (len < wd + 2 * PBo) { if (len > 0) pieces.push_back({a, z}); return; }
+            const int left = PBo * (((len - wd) / PBo) / 2);
+            rec(a, a + left, sep);
+            rec(a + left + wd, z, sep);
+            pieces.push_back({a + left, a + left + wd});
+        };
+        rec(0, Pf, sep_top);
+        perm.assign(Pf, 0);
+        int pos = 0;
+        for (auto& pc : pieces) for (int r = pc.first; r < pc.second; ++r) perm[r] = pos++;
+        return true;
+    };
+    // the coupling at TILE level in natural order, computed once: a candidate only re-maps tile indices when its pieces are
+    // whole tiles - they are not (the top separator absorbs the remainder), so the pose-level matrix is re-mapped per candidate
+    auto analyse = [&](const std::vector<int>& perm, int& depth, int& tiles) {
+        std::vector<uint8_t> z((size_t)NTo * NTo, 0);
+        for (int t = 0; t < NTo; ++t) z[(size_t)t * NTo + t] = 1;
+        if (use_cpl) {
+            for (int ri = 0; ri < Pf; ++ri) {
+                const int tx = perm[ri] / PBo;
+                const uint8_t* row = &cpl[(size_t)ri * Pf];
+                for (int rj = 0; rj <= ri; ++rj)
+                    if (row[rj]) { const int ty = perm[rj] / PBo; z[(size_t)std::max(tx, ty) * NTo + std::min(tx, ty)] = 1; }
+            }
+        } else {
+            std::vector<int> v;
+            for (int l = 0; l < b.Ltot; ++l) {
+                if (ba->lms[ba->lm_order[l]].fixed) continue;
+                v.clear();
+                for (int k = b.g_ptr[l]; k < b.g_ptr[l + 1]; ++k) { const int r = b.pose_red[b.g_pose[k]]; if (r >= 0) v.push_back(perm[r] / PBo); }
+                std::sort(v.begin(), v.end());
+                v.erase(std::unique(v.begin(), v.end()), v.end());
+                for (size_t x = 0; x < v.size(); ++x) for (size_t y = 0; y <= x; ++y) z[(size_t)v[x] * NTo + v[y]] = 1;
+            }
+        }
+        for (auto& e : pp) { const int x = perm[e.first] / PBo, y = perm[e.second] / PBo; z[(size_t)std::max(x, y) * NTo + std::min(x, y)] = 1; }
+        std::vector<int> rows;
+        for (int k = 0; k < NTo; ++k) {
+            rows.clear();
+            for (int i = k + 1; i < NTo; ++i) if (z[(size_t)i * NTo + k]) rows.push_back(i);
+            for (size_t x = 0; x < rows.size(); ++x) for (size_t y = 0; y <= x; ++y) z[(size_t)rows[x] * NTo + rows[y]] = 1;
+        }
+        std::vector<int> lev(NTo, 0);
+        depth = 0; tiles = 0;
+        for (int c = 0; c < NTo; ++c) {
+            for (int q = 0; q < c; ++q) if (z[(size_t)c * NTo + q]) { lev[c] = std::max(lev[c], lev[q] + 1); }
+            for (int q = 0; q <= c; ++q) tiles += z[(size_t)c * NTo + q];
+            depth = std::max(depth, lev[c] + 1);
+        }
+    };
+    // candidates: natural order and separators of 1 .. ceil(span / tile) tiles (a separator narrower than the longest track
+    // still gives a valid order - the few tracks that cross it only add dependencies); fewest levels, then fewest tiles.
+    // The candidates are independent: one thread each.
+    const int wmax = std::max(1, (span + PBo - 1) / PBo);
+    const int w_first = NTo > 256 ? std::min(wmax, 8) : 1, w_last = std::min(wmax, 8);
+    struct Cand { std::vector<int> perm; int depth = 0, tiles = 0; bool ok = false; };
+    std::vector<Cand> cands((size_t)std::max(w_last - w_first + 1, 0) + 1);
+    cands[0].perm = ba->red_perm; cands[0].ok = true;
+    for (int w = w_first; w <= w_last; ++w) {
+        Cand& c = cands[(size_t)(w - w_first) + 1];
+        c.ok = make_perm(w, c.perm);
+        if (!c.ok) break;
+    }
+    {
+        std::vector<std::thread> th;
+        for (size_t i = 1; i < cands.size(); ++i)
+            if (cands[i].ok) th.emplace_back([&, i]() { analyse(cands[i].perm, cands[i].depth, cands[i].tiles); });
+        analyse(cands[0].perm, cands[0].depth, cands[0].tiles);
+        for (auto& x : th) x.join();
+    }
+    size_t best = 0;
+    for (size_t i = 1; i < cands.size(); ++i)
+        if (cands[i].ok && (cands[i].depth < cands[best].depth || (cands[i].depth == cands[best].depth && cands[i].tiles < cands[best].tiles))) best = i;
+    ba->red_perm = cands[best].perm;
+    for (int sl = 0; sl < b.Pn; ++sl) if (b.pose_red[sl] >= 0) b.pose_red[sl] = ba->red_perm[b.pose_red[sl]];
+    for (int sl = 0; sl < b.Pn; ++sl) if (b.pose_red[sl] >= 0) b.red_slot[b.pose_red[sl]] = sl;
+}
+
+// ---- this rank's edges: lm-major (landmark, elimination index [fixed poses first], pose slot, insertion), pose-major copy ----
+int local_edges(Build& b)
+{
+    svi_ba* ba = b.ba;
+    const svi_ba_options& o = ba->opt;
+    // landmark sharding: contiguous slot ranges balanced by projection-edge count
+    auto bound = [&](int r) -> int {
+        if (r <= 0) return 0;
+        if (r >= o.n_ranks) return b.Ltot;
+        const int64_t want = b.Etot * r / o.n_ranks;
+        int s = (int)(std::lower_bound(b.g_ptr.begin(), b.g_ptr.end(), (int)want) - b.g_ptr.begin());
+        return std::min(std::max(s, 0), b.Ltot);
+    };
+    ba->E_total = b.Etot;
+    ba->L0 = bound(o.rank);
+    ba->L1 = bound(o.rank + 1);
+    b.L0 = ba->L0;
+    b.Ll = ba->L1 - ba->L0;
+    const int e0 = b.g_ptr[b.L0], e1 = b.g_ptr[ba->L1];
+    b.E = e1 - e0;
+    const int E = b.E, Ll = b.Ll, Pn = b.Pn;
+    std::vector<int> prank(Pn), pidx(Pn);
+    for (int s = 0; s < Pn; ++s) pidx[s] = s;
+    std::sort(pidx.begin(), pidx.end(), [&](int x, int y) { return b.pose_red[x] != b.pose_red[y] ? b.pose_red[x] < b.pose_red[y] : x < y; });
+    for (int r = 0; r < Pn; ++r) prank[pidx[r]] = r;
+    b.loc.assign(b.g_edge.begin() + e0, b.g_edge.begin() + e1);
+    b.e_pose.assign(b.g_pose.begin() + e0, b.g_pose.begin() + e1);
+    b.e_lm.resize(E);
+    b.lm_ptr.resize((size_t)Ll + 1);
+    for (int l = 0; l <= Ll; ++l) b.lm_ptr[l] = b.g_ptr[b.L0 + l] - e0;
+    int bad_lm = -1;
+    parallel_chunks((size_t)Ll, 1 << 13, [&](size_t la, size_t lz) {
+        for (size_t l = la; l < lz; ++l) {
+            const int a = b.lm_ptr[l], z = b.lm_ptr[l + 1];
+            if (z - a > kLmBlockEdges) { __atomic_store_n(&bad_lm, (int)l, __ATOMIC_RELAXED); continue; }
+            for (int i = a; i < z; ++i) b.e_lm[i] = (int)l;
+            for (int i = a + 1; i < z; ++i) { // by elimination rank; equal ranks cannot occur for distinct poses, ties keep insertion order
+                const int p = b.e_pose[i], e = b.loc[i], key = prank[p];
+                int j = i - 1;
+                while (j >= a && prank[b.e_pose[j]] > key) { b.e_pose[j + 1] = b.e_pose[j]; b.loc[j + 1] = b.loc[j]; --j; }
+                b.e_pose[j + 1] = p; b.loc[j + 1] = e;
+            }
+        }
+    });
+    if (bad_lm >= 0)
+        return fail(SVI_ERR_UNSUPPORTED, "landmark %lld has %d projection edges (limit %d)", (long long)ba->lms[ba->lm_order[b.L0 + bad_lm]].id,
+                    b.lm_ptr[bad_lm + 1] - b.lm_ptr[bad_lm], kLmBlockEdges);
+    // duplicate (pose, landmark) edges would alias one 6x6 block inside a Schur item; the reference never creates them (one
+    // measurement per landmark per keyframe), reject instead of mis-summing
+    for (int l = 0; l < Ll; ++l)
+        for (int a = b.lm_ptr[l] + 1; a < b.lm_ptr[l + 1]; ++a)
+            if (b.e_pose[a] == b.e_pose[a - 1])
+                return fail(SVI_ERR_UNSUPPORTED, "two projection edges between pose %lld and landmark %lld",
+                            (long long)ba->poses[ba->pose_order[b.e_pose[a]]].id, (long long)ba->lms[ba->lm_order[b.L0 + l]].id);
+    b.lb_lm.assign(1, 0);
+    for (int l = 0; l < Ll;) {
+        int l2 = l, edges = 0;
+        while (l2 < Ll && l2 - l < kLmBlockEdges && edges + (b.lm_ptr[l2 + 1] - b.lm_ptr[l2]) <= kLmBlockEdges) { edges += b.lm_ptr[l2 + 1] - b.lm_ptr[l2]; ++l2; }
+        b.lb_lm.push_back(l2);
+        l = l2;
+    }
+    b.n_lm_blocks = (int)b.lb_lm.size() - 1;
+    b.lm_fixed.resize(Ll);
+    for (int l = 0; l < Ll; ++l) b.lm_fixed[l] = (uint8_t)(ba->lms[ba->lm_order[b.L0 + l]].fixed ? 1 : 0);
+    // pose-major copy: free poses only, (pose slot, lm-major position): a stable counting sort
+    std::vector<int> cnt((size_t)Pn + 1, 0);
+    for (int k = 0; k < E; ++k) if (b.pose_red[b.e_pose[k]] >= 0) cnt[b.e_pose[k] + 1]++;
+    for (int s = 0; s < Pn; ++s) cnt[s + 1] += cnt[s];
+    b.Epm = cnt[Pn];
+    b.pm.resize(b.Epm);
+    {
+        std::vector<int> cur(cnt.begin(), cnt.end() - 1);
+        for (int k = 0; k < E; ++k) if (b.pose_red[b.e_pose[k]] >= 0) b.pm[cur[b.e_pose[k]]++] = k;
+    }
+    b.chunk_pose.clear(); b.chunk_begin.clear();
+    b.pose_chunk_ptr.assign((size_t)Pn + 1, 0);
+    for (int s = 0; s < Pn; ++s) {
+        b.pose_chunk_ptr[s] = (int)b.chunk_pose.size();
+        for (int k = cnt[s]; k < cnt[s + 1]; k += kPoseChunk) { b.chunk_pose.push_back(s); b.chunk_begin.push_back(k); }
+    }
+    b.pose_chunk_ptr[Pn] = (int)b.chunk_pose.size();
+    b.chunk_begin.push_back(b.Epm); // chunks are contiguous: chunk_begin[c+1] is the end of chunk c
+    b.n_chunks = (int)b.chunk_pose.size();
+    return SVI_OK;
+}
+
+// ---- pose-only / landmark-only edges -------------------------------------------------------------------------------------
+int aux_edges(Build& b)
+{
+    svi_ba* ba = b.ba;
+    const svi_ba_options& o = ba->opt;
+    const int Pn = b.Pn, Ll = b.Ll, L0 = b.L0;
+    std::vector<std::vector<int>> pose_aux(Pn);
+    if (o.rank == 0) {
+        for (const HSe3& e : ba->se3) {
+            const int k = (int)b.se3_i.size();
+            b.se3_i.push_back(b.pose_slot[e.i]); b.se3_j.push_back(b.pose_slot[e.j]);
+            b.se3_Z.insert(b.se3_Z.end(), e.Z, e.Z + 12);
+            b.se3_info.insert(b.se3_info.end(), e.info, e.info + 21);
+            b.se3_robust.push_back((uint8_t)(e.robust ? 1 : 0));
+            pose_aux[b.pose_slot[e.i]].push_back((k << 2) | 0);
+            pose_aux[b.pose_slot[e.j]].push_back((k << 2) | 1);
+        }
+        for (const HAcc& e : ba->acc) {
+            const int k = (int)b.acc_pose.size();
+            b.acc_pose.push_back(b.pose_slot[e.pose]);
+            for (int r = 0; r < 3; ++r) b.acc_a.push_back(e.off[3 * r] * e.a[0] + e.off[3 * r + 1] * e.a[1] + e.off[3 * r + 2] * e.a[2]);
+            b.acc_info.insert(b.acc_info.end(), e.info, e.info + 6);
+            pose_aux[b.pose_slot[e.pose]].push_back((k << 2) | 2);
+        }
+    }
+    b.pose_aux_ptr.assign((size_t)Pn + 1, 0);
+    for (int s = 0; s < Pn; ++s) {
+        b.pose_aux_ptr[s] = (int)b.pose_aux_ref.size();
+        b.pose_aux_ref.insert(b.pose_aux_ref.end(), pose_aux[s].begin(), pose_aux[s].end());
+    }
+    b.pose_aux_ptr[Pn] = (int)b.pose_aux_ref.size();
+    struct LL { int free_l; double ref[3], z[3], info[6]; uint8_t robust; };
+    std::vector<LL> v;
+    for (const HLL& e : ba->lmlm) {
+        const HLm &li = ba->lms[e.i], &lj = ba->lms[e.j];
+        if (!li.fixed && !lj.fixed)
+            return fail(SVI_ERR_UNSUPPORTED, "landmark-landmark edge %lld-%lld with two free ends (the reference fixes one, Cg2oOptimizer.cpp:445)",
+                        (long long)li.id, (long long)lj.id);
+        if (li.fixed && lj.fixed) continue;
+        LL x{};
+        const bool free_is_j = li.fixed != 0;
+        const HLm& fx = free_is_j ? li : lj;
+        const int s = b.lm_slot[free_is_j ? e.j : e.i];
+        if (s < L0 || s >= L0 + Ll) continue;
+        x.free_l = s - L0;
+        for (int c = 0; c < 3; ++c) { x.ref[c] = fx.p[c]; x.z[c] = free_is_j ? e.z[c] : -e.z[c]; }
+        memcpy(x.info, e.info, sizeof(x.info));
+        x.robust = (uint8_t)(e.robust ? 1 : 0);
+        v.push_back(x);
+    }
+    std::stable_sort(v.begin(), v.end(), [](const LL& x, const LL& y) { return x.free_l < y.free_l; });
+    for (const LL& x : v) {
+        b.ll_free.push_back(x.free_l);
+        b.ll_ref.insert(b.ll_ref.end(), x.ref, x.ref + 3);
+        b.ll_z.insert(b.ll_z.end(), x.z, x.z + 3);
+        b.ll_info.insert(b.ll_info.end(), x.info, x.info + 6);
+        b.ll_robust.push_back(x.robust);
+    }
+    b.lm_ll_ptr.assign((size_t)Ll + 1, 0);
+    for (int f : b.ll_free) b.lm_ll_ptr[f + 1]++;
+    for (int l = 0; l < Ll; ++l) b.lm_ll_ptr[l + 1] += b.lm_ll_ptr[l];
+    return SVI_OK;
+}
+
+// ---- reduced system tiling (identical on every rank: derived from the GLOBAL graph) ------------------------------------
+int tile_structure(Build& b)
+{
+    svi_ba* ba = b.ba;
+    const svi_ba_options& o = ba->opt;
+    b.TS = o.chol_tile > 0 ? o.chol_tile : 96;
+    if (b.TS % 48 != 0 || b.TS > kMaxTile) return fail(SVI_ERR_INVALID, "chol_tile must be 48 or 96");
+    const int TS = b.TS, PB = TS / 6;
+    b.PB = PB;
+    b.n = 6 * b.Pf;
+    const int NT = (b.n + TS - 1) / TS;
+    b.NT = NT;
+    std::vector<uint8_t> nz((size_t)NT * NT, 0);
+    for (int t = 0; t < NT; ++t) nz[(size_t)t * NT + t] = 1;
+    {
+        if (b.use_cpl) { // the pose-level coupling (natural reduced indices) mapped through the elimination order
+            const int Pf = b.Pf;
+            for (int ri = 0; ri < Pf; ++ri) {
+                const int tx = ba->red_perm[ri] / PB;
+                const uint8_t* row = &b.cpl[(size_t)ri * Pf];
+                for (int rj = 0; rj <= ri; ++rj)
+                    if (row[rj]) { const int ty = ba->red_perm[rj] / PB; nz[(size_t)std::max(tx, ty) * NT + std::min(tx, ty)] = 1; }
+            }
+        } else {
+            // tile chunks touched by every landmark of the global graph (a landmark's poses sit in one or two tiles almost always)
+            int v[kLmBlockEdges];
+            for (int l = 0; l < b.Ltot; ++l) {
+                if (ba->lms[ba->lm_order[l]].fixed) continue;
+                int m = 0;
+                for (int k = b.g_ptr[l]; k < b.g_ptr[l + 1]; ++k) {
+                    const int r = b.pose_red[b.g_pose[k]];
+                    if (r < 0) continue;
+                    const int t = r / PB;
+                    bool seen = false;
+                    for (int q = 0; q < m; ++q) if (v[q] == t) { seen = true; break; }
+                    if (!seen && m < kLmBlockEdges) v[m++] = t;
+                }
+                for (int x = 0; x < m; ++x)
+                    for (int y = 0; y < m; ++y) if (v[y] <= v[x]) nz[(size_t)v[x] * NT + v[y]] = 1;
+            }
+        }
+        for (const HSe3& e : ba->se3) {
+            const int ri = b.pose_red[b.pose_slot[e.i]], rj = b.pose_red[b.pose_slot[e.j]];
+            if (ri >= 0 && rj >= 0) { const int x = std::max(ri, rj) / PB, y = std::min(ri, rj) / PB; nz[(size_t)x * NT + y] = 1; }
+        }
+    }
+    const std::vector<uint8_t> nz_orig = nz; // tiles that receive Schur / pose-edge contributions (before fill-in)
+    // symbolic fill, right-looking over tile columns
+    b.h_col_ptr.assign((size_t)NT + 1, 0);
+    std::vector<std::pair<int, int>> col_rows; // (k, i)
+    std::vector<int> upd_i, upd_j, upd_k;
+    for (int k = 0; k < NT; ++k) {
+        std::vector<int> rows;
+        for (int i = k + 1; i < NT; ++i) if (nz[(size_t)i * NT + k]) rows.push_back(i);
+        b.h_col_ptr[k] = (int)col_rows.size();
+        for (int i : rows) col_rows.push_back({k, i});
+        for (size_t x = 0; x < rows.size(); ++x)
+            for (size_t y = 0; y <= x; ++y) {
+                nz[(size_t)rows[x] * NT + rows[y]] = 1;
+                upd_i.push_back(rows[x]); upd_j.push_back(rows[y]); upd_k.push_back(k);
+            }
+    }
+    b.h_col_ptr[NT] = (int)col_rows.size();
+    // tile ids: the tiles with contributions first, pure fill-in tiles after them - only the former (and g) have to cross the
+    // all-reduce, the latter are zero on every rank until the factorisation fills them
+    b.tile_map.assign((size_t)NT * NT, -1);
+    for (int pass = 0; pass < 2; ++pass)
+        for (int j = 0; j < NT; ++j)
+            for (int i = j; i < NT; ++i)
+                if (nz[(size_t)i * NT + j] && (nz_orig[(size_t)i * NT + j] != 0) == (pass == 0)) {
+                    b.tile_map[(size_t)i * NT + j] = (int)b.tile_ti.size(); b.tile_ti.push_back(i); b.tile_tj.push_back(j);
+                }
+    b.n_tiles = (int)b.tile_ti.size();
+    b.n_tiles_orig = 0;
+    for (size_t q = 0; q < nz_orig.size(); ++q) b.n_tiles_orig += nz_orig[q] ? 1 : 0;
+    b.diag_tile.resize(NT);
+    for (auto& kr : col_rows) { b.trsm_tile.push_back(b.tile_map[(size_t)kr.second * NT + kr.first]); b.trsm_row.push_back(kr.second); }
+    for (int k = 0; k < NT; ++k) b.diag_tile[k] = b.tile_map[(size_t)k * NT + k];
+    // dependency levels: column c waits for every column p < c with a tile (c,p); all columns of one level are factorised by
+    // one launch (ba_chol.hip).  The update of a diagonal tile by a column of the level just below is applied by the workgroup
+    // that factorises it ("pre" list); every other update is grouped by TARGET tile and runs in the launch that follows its
+    // source column's level, one workgroup set per target with the sources in ascending order (no two workgroups ever write
+    // the same tile: deterministic without atomics).
+    b.level.assign(NT, 0);
+    for (int c = 0; c < NT; ++c)
+        for (int q = 0; q < c; ++q) if (b.tile_map[(size_t)c * NT + q] >= 0) b.level[c] = std::max(b.level[c], b.level[q] + 1);
+    b.n_steps = NT ? *std::max_element(b.level.begin(), b.level.end()) + 1 : 0;
+    const int n_steps = b.n_steps;
+    b.h_step_ptr.assign((size_t)n_steps + 1, 0);
+    for (int st = 0; st < n_steps; ++st) {
+        b.h_step_ptr[st] = (int)b.step_col.size();
+        for (int c = 0; c < NT; ++c) if (b.level[c] == st) b.step_col.push_back(c);
+    }
+    b.h_step_ptr[n_steps] = (int)b.step_col.size();
+    b.pre_ptr.assign((size_t)NT + 1, 0);
+    for (int c = 0; c < NT; ++c) {
+        b.pre_ptr[c] = (int)b.pre_tile.size();
+        for (int q = 0; q < c; ++q)
+            if (b.tile_map[(size_t)c * NT + q] >= 0 && b.level[q] == b.level[c] - 1) { b.pre_tile.push_back(b.tile_map[(size_t)c * NT + q]); b.pre_col.push_back(q); }
+    }
+    b.pre_ptr[NT] = (int)b.pre_tile.size();
+    // target-grouped updates per launch step
+    b.h_tgt_ptr.assign((size_t)n_steps + 1, 0);
+    b.tgt_pair_ptr.assign(1, 0);
+    {
+        std::vector<std::vector<size_t>> by_step(n_steps);
+        for (size_t u = 0; u < upd_i.size(); ++u) {
+            const int i = upd_i[u], j = upd_j[u], q = upd_k[u];
+            if (i == j && b.level[q] == b.level[i] - 1) continue; // pre-update, done by the factorising workgroup
+            by_step[b.level[q] + 1].push_back(u);
+        }
+        for (int st = 0; st < n_steps; ++st) {
+            b.h_tgt_ptr[st] = (int)b.tgt_tile.size();
+            auto& v = by_step[st];
+            std::stable_sort(v.begin(), v.end(), [&](size_t x, size_t y) {
+                const int tx = b.tile_map[(size_t)upd_i[x] * NT + upd_j[x]], ty = b.tile_map[(size_t)upd_i[y] * NT + upd_j[y]];
+                return tx != ty ? tx < ty : upd_k[x] < upd_k[y];
+            });
+            int cur = -1;
+            for (size_t w = 0; w < v.size(); ++w) {
+                const size_t u = v[w];
+                const int tt = b.tile_map[(size_t)upd_i[u] * NT + upd_j[u]];
+                if (tt != cur) {
+                    b.tgt_tile.push_back(tt);
+                    b.tgt_row.push_back(upd_i[u] == upd_j[u] ? upd_i[u] : -1);
+                    b.tgt_pair_ptr.push_back(b.tgt_pair_ptr.back());
+                    cur = tt;
+                }
+                b.pair_a.push_back(b.tile_map[(size_t)upd_i[u] * NT + upd_k[u]]);
+                b.pair_b.push_back(b.tile_map[(size_t)upd_j[u] * NT + upd_k[u]]);
+                b.pair_src.push_back(upd_k[u]);
+                b.tgt_pair_ptr.back()++;
+            }
+        }
+        b.h_tgt_ptr[n_steps] = (int)b.tgt_tile.size();
+        const double t3 = (double)TS * TS * TS;
+        b.chol_flops = t3 / 3.0 * NT + t3 * (double)col_rows.size() + 2.0 * t3 * (double)upd_i.size();
+    }
+    b.h_trsm_ptr.assign((size_t)n_steps + 1, 0);
+    for (int st = 0; st < n_steps; ++st) {
+        b.h_trsm_ptr[st] = (int)b.st_tile.size();
+        for (int q = b.h_step_ptr[st]; q < b.h_step_ptr[st + 1]; ++q) {
+            const int c = b.step_col[q];
+            for (int w = b.h_col_ptr[c]; w < b.h_col_ptr[c + 1]; ++w) { b.st_tile.push_back(b.trsm_tile[w]); b.st_col.push_back(c); }
+        }
+    }
+    b.h_trsm_ptr[n_steps] = (int)b.st_tile.size();
+    if (b.dbg) {
+        for (int st = 0; st < n_steps; ++st) {
+            int mxpre = 0, mxpair = 0;
+            for (int q = b.h_step_ptr[st]; q < b.h_step_ptr[st + 1]; ++q) mxpre = std::max(mxpre, b.pre_ptr[b.step_col[q] + 1] - b.pre_ptr[b.step_col[q]]);
+            for (int t = b.h_tgt_ptr[st]; t < b.h_tgt_ptr[st + 1]; ++t) mxpair = std::max(mxpair, b.tgt_pair_ptr[t + 1] - b.tgt_pair_ptr[t]);
+            fprintf(stderr, "level %d: %d columns, max pre sources %d, %d update targets, max pairs per target %d, %d trsm tiles\n", st,
+                    b.h_step_ptr[st + 1] - b.h_step_ptr[st], mxpre, b.h_tgt_ptr[st + 1] - b.h_tgt_ptr[st], mxpair, b.h_trsm_ptr[st + 1] - b.h_trsm_ptr[st]);
+        }
+    }
+    return SVI_OK;
+}
+
+// ---- Schur decomposition: always on 48 x 48 sub-tiles (8 poses x 8 poses), whatever TS is ------------------------------
+// A stored 48 x 48 sub-tile is four CELLS of 4 x 4 poses (24 x 24); an item is one landmark in one cell: its edges to the
+// cell's row poses and to its column poses (masks over the four poses of each).  Cells of four poses instead of eight raise
+// the share of (pose, pose) lanes that have work from 36 % to 61 % at KITTI-like co-visibility.  A quarter job is a run of
+// <= L items of one cell, a wavefront job four quarter jobs of similar length (one per group of 16 lanes), so that the
+// four quarters of a wave finish together.
+int schur_work_lists(Build& b)
+{
+    svi_ba* ba = b.ba;
+    constexpr int PBS = 8, SUB = 48, PQ = 4;
+    const int TS = b.TS, NT = b.NT, Q = TS / SUB, NSUB = NT * Q, Ll = b.Ll;
+    // stored sub-tiles: every lower sub-tile inside a stored tile (they all have to be (re)written per trial)
+    std::vector<int> sub_map((size_t)NSUB * NSUB, -1);
+    for (int t = 0; t < b.n_tiles; ++t)
+        for (int sx = 0; sx < Q; ++sx)
+            for (int sy = 0; sy < Q; ++sy) {
+                const int cx = b.tile_ti[t] * Q + sx, cy = b.tile_tj[t] * Q + sy;
+                if (cy > cx) continue;
+                sub_map[(size_t)cx * NSUB + cy] = (int)b.sub_cx.size();
+                b.sub_cx.push_back(cx); b.sub_cy.push_back(cy); b.sub_tile.push_back(t);
+            }
+    b.n_sub = (int)b.sub_cx.size();
+    const int n_cells = 4 * b.n_sub;
+    // the segments of a landmark: runs of its free-pose edges inside one group of four reduced poses
+    struct Seg { int chunk, begin, mask, count; };
+    auto segments = [&](int l, Seg* seg) -> int {
+        int a = b.lm_ptr[l];
+        const int end = b.lm_ptr[l + 1];
+        while (a < end && b.pose_red[b.e_pose[a]] < 0) ++a; // edges to fixed poses come first
+        int ns = 0;
+        while (a < end) {
+            const int c = b.pose_red[b.e_pose[a]] / PQ;
+            Seg sg{c, a, 0, 0};
+            while (a < end && b.pose_red[b.e_pose[a]] / PQ == c) { sg.mask |= 1 << (b.pose_red[b.e_pose[a]] % PQ); ++sg.count; ++a; }
+            seg[ns++] = sg;
+        }
+        return ns;
+    };
+    // pass 1: items per cell and thread (a thread = a contiguous range of landmarks);  pass 2: the items straight into their
+    // cell's range, threads in landmark order inside a cell (= a stable sort by cell, landmarks ascending)
+    unsigned hw = std::thread::hardware_concurrency();
+    const int NTH = (int)std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)8, (size_t)std::max(Ll / 8192, 1)});
+    std::vector<std::vector<int>> hist(NTH, std::vector<int>((size_t)n_cells, 0));
+    std::vector<int> terr(NTH, 0);
+    std::vector<int64_t> tpairs(NTH, 0);
+    auto lrange = [&](int t, int& la, int& lz) { const int per = (Ll + NTH - 1) / NTH; la = std::min(Ll, t * per); lz = std::min(Ll, (t + 1) * per); };
+    auto run_threads = [&](auto&& body) {
+        std::vector<std::thread> th;
+        for (int t = 1; t < NTH; ++t) th.emplace_back([&body, t]() { body(t); });
+        body(0);
+        for (auto& x : th) x.join();
+    };
+    run_threads([&](int t) {
+        int la, lz;
+        lrange(t, la, lz);
+        Seg seg[kLmBlockEdges];
+        int* h = hist[t].data();
+        for (int l = la; l < lz; ++l) {
+            if (b.lm_fixed[l]) continue;
+            const int ns = segments(l, seg);
+            for (int x = 0; x < ns; ++x)
+                for (int y = 0; y <= x; ++y) {
+                    const int qx = seg[x].chunk, qy = seg[y].chunk; // qx >= qy: edges of a landmark ascend in reduced index
+                    if (qy > qx) { terr[t] = 1; continue; }
+                    const int sub = sub_map[(size_t)(qx / 2) * NSUB + qy / 2];
+                    if (sub < 0) { terr[t] = 2; continue; }
+                    h[4 * sub + 2 * (qx % 2) + (qy % 2)]++;
+                    tpairs[t] += (x == y) ? (int64_t)seg[x].count * (seg[x].count + 1) / 2 : (int64_t)seg[x].count * seg[y].count;
+                }
+        }
+    });
+    int64_t pairs = 0;
+    for (int t = 0; t < NTH; ++t) {
+        if (terr[t] == 1) return fail(SVI_ERR_STATE, "internal: landmark edges not in reduced pose order");
+        if (terr[t] == 2) return fail(SVI_ERR_STATE, "internal: Schur sub-tile outside the tile structure");
+        pairs += tpairs[t];
+    }
+    b.total_pairs = pairs;
+    std::vector<int> cell_ptr((size_t)n_cells + 1, 0);
+    {
+        int run = 0;
+        for (int c = 0; c < n_cells; ++c) {
+            cell_ptr[c] = run;
+            for (int t = 0; t < NTH; ++t) { const int k = hist[t][c]; hist[t][c] = run; run += k; } // now: the thread's cursor in the cell
+        }
+        cell_ptr[n_cells] = run;
+    }
+    b.n_items = cell_ptr[n_cells];
+    b.it_pack.resize((size_t)4 * std::max(b.n_items, 1));
+    run_threads([&](int t) {
+        int la, lz;
+        lrange(t, la, lz);
+        Seg seg[kLmBlockEdges];
+        int* cur = hist[t].data();
+        for (int l = la; l < lz; ++l) {
+            if (b.lm_fixed[l]) continue;
+            const int ns = segments(l, seg);
+            for (int x = 0; x < ns; ++x)
+                for (int y = 0; y <= x; ++y) {
+                    const int qx = seg[x].chunk, qy = seg[y].chunk;
+                    const int sub = sub_map[(size_t)(qx / 2) * NSUB + qy / 2];
+                    int* r = &b.it_pack[(size_t)4 * cur[4 * sub + 2 * (qx % 2) + (qy % 2)]++];
+                    r[0] = l; r[1] = seg[x].begin; r[2] = seg[y].begin; r[3] = seg[x].mask | (seg[y].mask << 8);
+                }
+        }
+    });
+    // quarter jobs: as many as fit on the chip at once - the kernel holds two waves per SIMD (214 VGPRs, 59 KB of LDS per
+    // workgroup), one more would wait for a whole round.  Measured at config 4 with the current kernels (quarter jobs: Schur +
+    // assemble us): 4096: 207 + 22, 6144: 185 + 27, 8192: 176 + 33, 10240: 209 + 38.
+    int n_cu = 256;
+    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ba->opt.device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
+    const int64_t qj_cap = (int64_t)4 * (n_cu * 4 * 2);
+    auto pieces = [&](int len) { int64_t cnt = 0; for (int c = 0; c < n_cells; ++c) cnt += (cell_ptr[c + 1] - cell_ptr[c] + len - 1) / len; return cnt; };
+    int L = 16;
+    while (L < 1024 && pieces(L) > qj_cap) ++L;
+    struct QJob { int begin, end, cell; };
+    std::vector<QJob> qjobs;
+    for (int c = 0; c < n_cells; ++c)
+        for (int i = cell_ptr[c]; i < cell_ptr[c + 1]; i += L) qjobs.push_back({i, std::min(i + L, cell_ptr[c + 1]), c});
+    // waves take four quarter jobs of similar length; the slabs of a cell are summed in the order of its pieces
+    std::vector<int> qorder(qjobs.size());
+    for (size_t i = 0; i < qorder.size(); ++i) qorder[i] = (int)i;
+    std::stable_sort(qorder.begin(), qorder.end(), [&](int x, int y) { return qjobs[x].end - qjobs[x].begin > qjobs[y].end - qjobs[y].begin; });
+    b.n_jobs = ((int)qjobs.size() + 3) / 4;
+    const size_t nq4 = (size_t)4 * std::max(b.n_jobs, 1);
+    b.qj_begin.assign(nq4, 0); b.qj_end.assign(nq4, 0); b.qj_diag.assign(nq4, 0);
+    b.job_len.assign(std::max(b.n_jobs, 1), 0);
+    std::vector<int> slot_of(qjobs.size(), -1);
+    for (size_t k = 0; k < qorder.size(); ++k) {
+        const QJob& q = qjobs[qorder[k]];
+        b.qj_begin[k] = q.begin; b.qj_end[k] = q.end;
+        const int sub = q.cell / 4, u = (q.cell / 2) % 2, v = q.cell % 2;
+        b.qj_diag[k] = (b.sub_cx[sub] == b.sub_cy[sub] && u == v) ? 1 : 0;
+        b.job_len[k / 4] = std::max(b.job_len[k / 4], q.end - q.begin);
+        slot_of[qorder[k]] = (int)k;
+    }
+    b.cell_qj_ptr.assign((size_t)n_cells + 1, 0);
+    {
+        size_t k = 0;
+        for (int c = 0; c < n_cells; ++c) {
+            b.cell_qj_ptr[c] = (int)b.cell_qj.size();
+            while (k < qjobs.size() && qjobs[k].cell == c) { b.cell_qj.push_back(slot_of[k]); ++k; } // qjobs ascend in cell
+        }
+        b.cell_qj_ptr[n_cells] = (int)b.cell_qj.size();
+    }
+    std::vector<std::vector<int>> taux(b.n_sub);
+    for (int k = 0; k < (int)b.se3_i.size(); ++k) {
+        const int ri = b.pose_red[b.se3_i[k]], rj = b.pose_red[b.se3_j[k]];
+        if (ri < 0 || rj < 0 || ri == rj) continue;
+        const int tr = ri > rj ? 0 : 1; // row pose = the one with the larger reduced index
+        const int hi = std::max(ri, rj), lo = std::min(ri, rj);
+        const int sub = sub_map[(size_t)(hi / PBS) * NSUB + lo / PBS];
+        if (sub < 0) return fail(SVI_ERR_STATE, "internal: odometry block outside the tile structure");
+        taux[sub].push_back((k << 1) | tr);
+    }
+    b.sub_aux_ptr.assign((size_t)b.n_sub + 1, 0);
+    for (int t = 0; t < b.n_sub; ++t) {
+        b.sub_aux_ptr[t] = (int)b.sub_aux_ref.size();
+        b.sub_aux_ref.insert(b.sub_aux_ref.end(), taux[t].begin(), taux[t].end());
+    }
+    b.sub_aux_ptr[b.n_sub] = (int)b.sub_aux_ref.size();
+    return SVI_OK;
+}
+
+int upload(Build& b)
+{
+    svi_ba* ba = b.ba;
+    BaDev& d = ba->d;
+    const svi_ba_options& o = ba->opt;
+    Uploader up{ba};
+    const int Pn = b.Pn, Pf = b.Pf, Ll = b.Ll, E = b.E, TS = b.TS, NT = b.NT, n_tiles = b.n_tiles, n_jobs = b.n_jobs, n_sub = b.n_sub;
+    d.Pn = Pn; d.Pf = Pf; d.Ll = Ll; d.E = E;
+    d.n_lm_blocks = b.n_lm_blocks; d.n_chunks = b.n_chunks;
+    d.n_se3 = (int)b.se3_i.size(); d.n_accel = (int)b.acc_pose.size(); d.n_lmlm = (int)b.ll_free.size();
+    d.info_planes = b.planes;
+    std::vector<double> hp((size_t)12 * Pn), hl((size_t)3 * Ll);
+    for (int s = 0; s < Pn; ++s) memcpy(&hp[(size_t)12 * s], ba->poses[ba->pose_order[s]].T, 96);
+    for (int l = 0; l < Ll; ++l) memcpy(&hl[(size_t)3 * l], ba->lms[ba->lm_order[b.L0 + l]].p, 24);
+    for (int q = 0; q < 2; ++q) {
+        const double* p = nullptr;
+        SVI_TRY(up.up(hp, &p)); d.pose[q] = const_cast<double*>(p);
+        SVI_TRY(up.up(hl, &p)); d.lm[q] = const_cast<double*>(p);
+    }
+    SVI_TRY(up.up(b.pose_red, &d.pose_red));
+    SVI_TRY(up.up(b.lm_fixed, &d.lm_fixed));
+    SVI_TRY(up.up(b.e_pose, &d.e_pose));
+    SVI_TRY(up.up(b.e_lm, &d.e_lm));
+    SVI_TRY(up.up(b.lm_ptr, &d.lm_ptr));
+    SVI_TRY(up.up(b.lb_lm, &d.lb_lm));
+    {
+        const int* p = nullptr;
+        SVI_TRY(up.up(b.red_slot, &p)); ba->red_slot = const_cast<int*>(p);
+        SVI_TRY(up.up(b.loc, &p)); ba->e_orig = const_cast<int*>(p);
+    }
+    // the edge values, laid out by two gather kernels from the device-side log
+    const int np2 = (3 + b.planes + 1) / 2; // double2 planes of the packed [z | information | pad] record
+    {
+        const int* pm_dev = nullptr;
+        SVI_TRY(up.up(b.pm, &pm_dev));
+        double *zi = nullptr, *pzi = nullptr;
+        uint8_t *fl = nullptr, *pfl = nullptr;
+        int* pml = nullptr;
+        SVI_TRY(up.alloc((size_t)2 * np2 * std::max(E, 1), &zi, false));
+        SVI_TRY(up.alloc((size_t)std::max(E, 1), &fl, false));
+        SVI_TRY(up.alloc((size_t)2 * np2 * std::max(E, 1), &pzi, false)); // the pose-major copy uses the same plane stride E (the kernels share load_edge)
+        SVI_TRY(up.alloc((size_t)std::max(E, 1), &pfl, false));
+        SVI_TRY(up.alloc((size_t)std::max(E, 1), &pml, false));
+        ba_gather_edges(ba->raw_log.as<double>(), ba->raw_flags.as<uint8_t>(), ba->e_orig, nullptr, E, E, b.planes, zi, fl, nullptr, nullptr, ba->stream);
+        ba_gather_edges(ba->raw_log.as<double>(), ba->raw_flags.as<uint8_t>(), ba->e_orig, pm_dev, b.Epm, E, b.planes, pzi, pfl, d.e_lm, pml, ba->stream);
+        SVI_HIP(hipGetLastError());
+        d.e_zi = zi; d.e_flags = fl; d.pm_zi = pzi; d.pm_flags = pfl; d.pm_lm = pml;
+    }
+    SVI_TRY(up.up(b.chunk_pose, &d.chunk_pose));
+    SVI_TRY(up.up(b.chunk_begin, &d.chunk_begin));
+    SVI_TRY(up.up(b.pose_chunk_ptr, &d.pose_chunk_ptr));
+    SVI_TRY(up.up(b.se3_i, &d.se3_i));
+    SVI_TRY(up.up(b.se3_j, &d.se3_j));
+    SVI_TRY(up.up(b.se3_Z, &d.se3_Z));
+    SVI_TRY(up.up(b.se3_info, &d.se3_info));
+    SVI_TRY(up.up(b.se3_robust, &d.se3_robust));
+    SVI_TRY(up.up(b.acc_pose, &d.acc_pose));
+    SVI_TRY(up.up(b.acc_a, &d.acc_a));
+    SVI_TRY(up.up(b.acc_info, &d.acc_info));
+    SVI_TRY(up.up(b.ll_free, &d.ll_free));
+    SVI_TRY(up.up(b.ll_ref, &d.ll_ref));
+    SVI_TRY(up.up(b.ll_z, &d.ll_z));
+    SVI_TRY(up.up(b.ll_info, &d.ll_info));
+    SVI_TRY(up.up(b.ll_robust, &d.ll_robust));
+    SVI_TRY(up.up(b.lm_ll_ptr, &d.lm_ll_ptr));
+    SVI_TRY(up.up(b.pose_aux_ptr, &d.pose_aux_ptr));
+    SVI_TRY(up.up(b.pose_aux_ref, &d.pose_aux_ref));
+    SVI_TRY(up.alloc((size_t)12 * E, &d.NZ));
+    SVI_TRY(up.alloc((size_t)6 * Ll, &d.Hll));
+    SVI_TRY(up.alloc((size_t)3 * Ll, &d.bl));
+    SVI_TRY(up.alloc((size_t)6 * Ll, &d.Hinv));
+    SVI_TRY(up.alloc((size_t)12 * std::max(Ll, 1), &d.HinvB));
+    SVI_TRY(up.alloc((size_t)27 * b.n_chunks, &d.chunk_out));
+    SVI_TRY(up.alloc((size_t)120 * d.n_se3, &d.se3_out));
+    SVI_TRY(up.alloc((size_t)42 * d.n_accel, &d.acc_out));
+    d.lin_count = 27 * Pf + 2 + o.n_ranks;
+    SVI_TRY(up.alloc((size_t)d.lin_count, &d.lin_buf));
+    d.Hpp = d.lin_buf; d.bp = d.lin_buf + (size_t)21 * Pf; d.lin_scal = d.lin_buf + (size_t)27 * Pf;
+    SVI_TRY(up.alloc((size_t)16 * std::max(b.n_lm_blocks, 1), &d.block_part));
+    d.TS = TS; d.NT = NT; d.n_tiles = n_tiles;
+    SVI_TRY(up.up(b.tile_map, &d.tile_map));
+    // [ g | tiles with contributions | fill-in tiles ]: the all-reduce payload is the prefix g + contributing tiles
+    d.red_count = NT * TS + b.n_tiles_orig * TS * TS;
+    SVI_TRY(up.alloc(2 + (size_t)NT * TS + (size_t)n_tiles * TS * TS, &d.red_base)); // two doubles in front: see linearize()
+    d.g = d.red_base + 2;
+    d.S = d.g + (size_t)NT * TS;
+    SVI_TRY(up.alloc((size_t)n_tiles * TS * TS, &d.Lt));
+    SVI_TRY(up.alloc((size_t)NT * TS * TS, &d.Linv));
+    SVI_TRY(up.alloc((size_t)NT * TS, &d.dx));
+    SVI_TRY(up.alloc(1, &d.chol_status));
+    d.n_items = b.n_items; d.n_jobs = n_jobs; d.n_sub = n_sub;
+    SVI_TRY(up.up(b.it_pack, &d.it_pack));
+    SVI_TRY(up.up(b.qj_begin, &d.qj_begin));
+    SVI_TRY(up.up(b.qj_end, &d.qj_end));
+    SVI_TRY(up.up(b.qj_diag, &d.qj_diag));
+    SVI_TRY(up.up(b.job_len, &d.job_len));
+    SVI_TRY(up.alloc((size_t)std::max(n_jobs, 1) * 36 * 64, &d.slab, false));
+    SVI_TRY(up.alloc((size_t)std::max(n_jobs, 1) * 4 * 6 * 4, &d.gslab, false));
+    SVI_TRY(up.up(b.cell_qj_ptr, &d.cell_qj_ptr));
+    SVI_TRY(up.up(b.cell_qj, &d.cell_qj));
+    SVI_TRY(up.up(b.sub_cx, &d.sub_cx));
+    SVI_TRY(up.up(b.sub_cy, &d.sub_cy));
+    SVI_TRY(up.up(b.sub_tile, &d.sub_tile));
+    SVI_TRY(up.up(b.sub_aux_ptr, &d.sub_aux_ptr));
+    SVI_TRY(up.up(b.sub_aux_ref, &d.sub_aux_ref));
+    d.add_pose_terms = d.add_aux_blocks = (o.rank == 0) ? 1 : 0;
+    d.lin_from_red = 0;
+    SVI_TRY(up.alloc(16, &d.scal));
+    d.aux_blocks = std::max(1, (std::max(d.n_se3, d.n_accel) + 63) / 64);
+    SVI_TRY(up.alloc((size_t)2 * d.aux_blocks, &d.aux_part));
+    SVI_TRY(up.alloc(1, &d.aux_count));
+    if (o.n_ranks > 1) SVI_TRY(up.alloc((size_t)3 * b.Ltot, &ba->lm_all));
+
+    CholPlan& p = ba->plan;
+    p.TS = TS; p.NT = NT; p.n_steps = b.n_steps;
+    ba->h_step_ptr = b.h_step_ptr; ba->h_tgt_ptr = b.h_tgt_ptr; ba->h_trsm_ptr = b.h_trsm_ptr;
+    p.h_step_ptr = ba->h_step_ptr.data(); p.h_tgt_ptr = ba->h_tgt_ptr.data(); p.h_trsm_ptr = ba->h_trsm_ptr.data();
+    SVI_TRY(up.up(b.h_col_ptr, &p.col_ptr));
+    SVI_TRY(up.up(b.trsm_tile, &p.trsm_tile));
+    SVI_TRY(up.up(b.trsm_row, &p.trsm_row));
+    SVI_TRY(up.up(b.step_col, &p.step_col));
+    {
+        // everything a chain / back-substitution workgroup needs to know about its column in ONE record (two 16-byte loads
+        // side by side instead of a chain of three dependent index loads at the start of every launch)
+        std::vector<int> step_desc((size_t)8 * std::max<size_t>(b.step_col.size(), 1), 0);
+        for (size_t q = 0; q < b.step_col.size(); ++q) {
+            const int c = b.step_col[q];
+            int* r = &step_desc[8 * q];
+            r[0] = c; r[1] = b.diag_tile[c]; r[2] = b.pre_ptr[c]; r[3] = b.pre_ptr[c + 1] - b.pre_ptr[c];
+            r[4] = b.h_col_ptr[c]; r[5] = b.h_col_ptr[c + 1] - b.h_col_ptr[c];
+        }
+        SVI_TRY(up.up(step_desc, &p.step_desc));
+        SVI_TRY(up.up(b.diag_tile, &p.diag_tile));
+        SVI_TRY(up.up(b.pre_ptr, &p.pre_ptr));
+        SVI_TRY(up.up(b.pre_tile, &p.pre_tile));
+        SVI_TRY(up.up(b.pre_col, &p.pre_col));
+        SVI_TRY(up.up(b.tgt_tile, &p.tgt_tile));
+        SVI_TRY(up.up(b.tgt_row, &p.tgt_row));
+        SVI_TRY(up.up(b.tgt_pair_ptr, &p.tgt_pair_ptr));
+        SVI_TRY(up.up(b.pair_a, &p.pair_a));
+        SVI_TRY(up.up(b.pair_b, &p.pair_b));
+        SVI_TRY(up.up(b.pair_src, &p.pair_src));
+        SVI_TRY(up.up(b.st_tile, &p.st_tile));
+        SVI_TRY(up.up(b.st_col, &p.st_col));
+        if (!ba->h_scal) SVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&ba->h_scal), 16 * sizeof(double)));
+        if (!ba->h_status) SVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&ba->h_status), sizeof(int) * 4));
+        ba->h_status[0] = ba->h_status[1] = 0;
+        ba->pub_seq = 0;
+        ba_configure_kernels(TS);
+        // the host vectors of this call are read by the copies above: drain before they go out of scope
+        SVI_HIP(hipStreamSynchronize(ba->stream));
+    }
+    return SVI_OK;
+}
+
+} // namespace
+
+namespace svi {
+
+// the graph is the one the device structures were built for: only the estimates go back to the device
+int reupload_state(svi_ba* ba)
+{
+    BaDev& d = ba->d;
+    std::vector<double> hp((size_t)12 * d.Pn), hl((size_t)3 * std::max(d.Ll, 1));
+    for (int s = 0; s < d.Pn; ++s) memcpy(&hp[(size_t)12 * s], ba->poses[ba->pose_order[s]].T, 96);
+    for (int l = 0; l < d.Ll; ++l) memcpy(&hl[(size_t)3 * l], ba->lms[ba->lm_order[ba->L0 + l]].p, 24);
+    for (int q = 0; q < 2; ++q) {
+        if (d.Pn) SVI_HIP(hipMemcpyAsync(d.pose[q], hp.data(), sizeof(double) * 12 * d.Pn, hipMemcpyHostToDevice, ba->stream));
+        if (d.Ll) SVI_HIP(hipMemcpyAsync(d.lm[q], hl.data(), sizeof(double) * 3 * d.Ll, hipMemcpyHostToDevice, ba->stream));
+    }
+    SVI_HIP(hipMemsetAsync(d.chol_status, 0, sizeof(int), ba->stream));
+    SVI_HIP(hipMemsetAsync(d.aux_count, 0, sizeof(int), ba->stream));
+    ba->h_status[0] = ba->h_status[1] = 0;
+    ba->pub_seq = 0;
+    ba->lin_local = false;
+    SVI_HIP(hipStreamSynchronize(ba->stream));
+    return SVI_OK;
+}
+
+int build_structure(svi_ba* ba)
+{
+    Build b;
+    b.ba = ba;
+    b.dbg = getenv("SVI_DEBUG_PLAN") != nullptr;
+    b.t0 = std::chrono::steady_clock::now();
+    BaDev& d = ba->d;
+    const svi_ba_options& o = ba->opt;
+    d.fx = o.fx; d.fy = o.fy; d.cx = o.cx; d.cy = o.cy; d.cauchy_delta = o.cauchy_delta;
+    b.mark(0);
+    SVI_TRY(edges_flush(ba));      // whatever the add_* calls have not sent yet travels while the host sorts
+    order_vertices(b);
+    b.mark(1);
+    sort_edges(b);
+    b.mark(2);
+    pose_coupling(b);
+    elimination_order(b);
+    b.mark(3);
+    SVI_TRY(local_edges(b));
+    b.mark(4);
+    SVI_TRY(aux_edges(b));
+    b.mark(5);
+    SVI_TRY(tile_structure(b));
+    b.mark(6);
+    SVI_TRY(schur_work_lists(b));
+    b.mark(7);
+    SVI_TRY(upload(b));
+    b.mark(8);
+
+    svi_ba_stats& st = ba->stats;
+    const uint64_t it0 = st.lm_iterations, tr0 = st.lm_trials, cf0 = st.chol_failures;
+    st = svi_ba_stats{};
+    st.lm_iterations = it0; st.lm_trials = tr0; st.chol_failures = cf0;
+    st.n_poses = b.Pn; st.n_poses_free = b.Pf; st.n_landmarks = b.Ltot; st.n_landmarks_local = b.Ll;
+    st.n_edges_proj = b.Etot; st.n_edges_proj_local = b.E;
+    st.n_edges_se3 = (int64_t)ba->se3.size(); st.n_edges_accel = (int64_t)ba->acc.size(); st.n_edges_lmlm = (int64_t)ba->lmlm.size();
+    st.n_schur_tiles = b.n_jobs; st.n_window_blocks = b.total_pairs;
+    st.chol_n = b.n; st.chol_tile = b.TS; st.chol_tiles_nnz = b.n_tiles; st.chol_steps = b.n_steps;
+    st.reduce_doubles = d.red_count;
+    st.chol_flops = b.chol_flops;
+    return SVI_OK;
+}
+
+} // namespace svi
