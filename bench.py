@@ -87,13 +87,21 @@ def bench_optimize_call(svi, prob, device, label):
     t2 = time.perf_counter()
     ba.apply_optimization()
     t3 = time.perf_counter()
-    # the second call on the same (unchanged) handle: what re-initialising costs when the structures are warm
+    # a second call on the unchanged graph (only the estimates go back to the device) ...
     ba.initialize()
     t4 = time.perf_counter()
+    # ... and one after an edit (a landmark without edges joins): the whole structure analysis again, on warm device buffers -
+    # what every later Cg2oOptimizer::optimize of a growing map pays
+    ba.add_landmark(987654321, [0.0, 0.0, 5.0])
+    t5 = time.perf_counter()
+    ba.initialize()
+    t6 = time.perf_counter()
     ba.close()
     return {"workload": label, "initialize_ms": 1e3 * (t1 - t0), "optimize_until_ms": 1e3 * (t2 - t1), "write_back_ms": 1e3 * (t3 - t2),
             "total_ms": 1e3 * (t3 - t0), "iterations_nominal": int(nominal), "iterations_executed": int(executed),
-            "reinitialize_ms": 1e3 * (t4 - t3)}
+            "reinitialize_unchanged_graph_ms": 1e3 * (t4 - t3), "reinitialize_after_edit_ms": 1e3 * (t6 - t5),
+            "note": "initialize_ms is the first call on a fresh handle (device buffers allocated); the edge values were sent to the "
+                    "device-side log by the add_* calls of the graph construction, which is not in these numbers"}
 
 
 def bench_config3(svi, device, steps=20, warmup=5):

@@ -42,10 +42,20 @@ namespace {
 #define SVI_TRY(x) do { int rc_ = (x); if (rc_ != SVI_OK) return rc_; } while (0)
 
 // f(begin, end) over contiguous chunks of [0, n) on up to 8 threads (the caller's thread takes the first chunk)
+size_t max_threads()
+{
+    static const size_t n = []() {
+        const char* e = getenv("SVI_HOST_THREADS");
+        if (e && atoi(e) > 0) return (size_t)atoi(e);
+        unsigned hw = std::thread::hardware_concurrency();
+        return std::min<size_t>(hw ? hw : 1, 8);
+    }();
+    return n;
+}
+
 template <class F> void parallel_chunks(size_t n, size_t min_chunk, F&& f)
 {
-    unsigned hw = std::thread::hardware_concurrency();
-    size_t nt = std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)8, std::max<size_t>(n / std::max<size_t>(min_chunk, 1), 1)});
+    size_t nt = std::min<size_t>(max_threads(), std::max<size_t>(n / std::max<size_t>(min_chunk, 1), 1));
     if (nt <= 1) { f((size_t)0, n); return; }
     std::vector<std::thread> th;
     const size_t per = (n + nt - 1) / nt;
@@ -649,6 +659,7 @@ int schur_work_lists(Build& b)
             }
     b.n_sub = (int)b.sub_cx.size();
     const int n_cells = 4 * b.n_sub;
+    b.mark(61);
     // the segments of a landmark: runs of its free-pose edges inside one group of four reduced poses
     struct Seg { int chunk, begin, mask, count; };
     auto segments = [&](int l, Seg* seg) -> int {
@@ -666,8 +677,7 @@ int schur_work_lists(Build& b)
     };
     // pass 1: items per cell and thread (a thread = a contiguous range of landmarks);  pass 2: the items straight into their
     // cell's range, threads in landmark order inside a cell (= a stable sort by cell, landmarks ascending)
-    unsigned hw = std::thread::hardware_concurrency();
-    const int NTH = (int)std::min<size_t>({(size_t)(hw ? hw : 1), (size_t)8, (size_t)std::max(Ll / 8192, 1)});
+    const int NTH = (int)std::min<size_t>(max_threads(), (size_t)std::max(Ll / 8192, 1));
     std::vector<std::vector<int>> hist(NTH, std::vector<int>((size_t)n_cells, 0));
     std::vector<int> terr(NTH, 0);
     std::vector<int64_t> tpairs(NTH, 0);
@@ -697,6 +707,7 @@ int schur_work_lists(Build& b)
                 }
         }
     });
+    b.mark(62);
     int64_t pairs = 0;
     for (int t = 0; t < NTH; ++t) {
         if (terr[t] == 1) return fail(SVI_ERR_STATE, "internal: landmark edges not in reduced pose order");
@@ -714,7 +725,9 @@ int schur_work_lists(Build& b)
         cell_ptr[n_cells] = run;
     }
     b.n_items = cell_ptr[n_cells];
+    b.mark(63);
     b.it_pack.resize((size_t)4 * std::max(b.n_items, 1));
+    b.mark(64);
     run_threads([&](int t) {
         int la, lz;
         lrange(t, la, lz);
@@ -732,6 +745,7 @@ int schur_work_lists(Build& b)
                 }
         }
     });
+    b.mark(65);
     // quarter jobs: as many as fit on the chip at once - the kernel holds two waves per SIMD (214 VGPRs, 59 KB of LDS per
     // workgroup), one more would wait for a whole round.  Measured at config 4 with the current kernels (quarter jobs: Schur +
     // assemble us): 4096: 207 + 22, 6144: 185 + 27, 8192: 176 + 33, 10240: 209 + 38.
