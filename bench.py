@@ -379,6 +379,9 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=30)
     ap.add_argument("--chol-tile", type=int, default=96)
     ap.add_argument("--backend", default="nccl")
+    ap.add_argument("--hook", choices=("native", "torch"), default="native",
+                    help="N > 1: the all-reduce of the reduced system through the library's own RCCL communicator (C++, svi_rccl_*) or "
+                         "through torch.distributed (the gloo rehearsal always uses torch)")
     args = ap.parse_args()
 
     import torch
@@ -405,14 +408,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    native = None
+    hook_used = "none"
+    if world > 1:
+        hook_used = "torch.distributed"
+        if args.hook == "native" and args.backend == "nccl":
+            try:
+                native = sdist.NativeRccl(rank, world, local)
+                hook_used = "native RCCL (svi_rccl_allreduce)"
+            except Exception as e:  # noqa: BLE001
+                print("rank %d: native RCCL hook unavailable (%s): using torch.distributed" % (rank, e), file=sys.stderr)
+                native = None
+        # every rank must take the same path
+        flag = torch.tensor([1 if native is not None else 0], device="cpu" if args.backend == "gloo" else "cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            native, hook_used = None, "torch.distributed"
+
+    def attach(ba):
+        if world > 1:
+            if native is not None:
+                ba.set_allreduce_native(native)
+            else:
+                ba.set_allreduce(sdist.make_allreduce_hook())
+
     def measure(prob, steps, warmup):
         """one handle per rank over `prob` (landmark-sharded `world` ways), W untimed + K timed LM iterations"""
         cam = prob["cam"]
         ba = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"], device=local, rank=rank, n_ranks=world,
                                 chol_tile=args.chol_tile)
         stored = synth.build_ba_graph(ba, prob)
-        if world > 1:
-            ba.set_allreduce(sdist.make_allreduce_hook())
+        attach(ba)
         ba.initialize()
         run_exact(ba, warmup)
         s0 = ba.stats()
@@ -458,8 +484,7 @@ def main():
         ba = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"], device=local, rank=rank,
                                 n_ranks=world, chol_tile=args.chol_tile, **kw)
         synth.build_ba_graph(ba, prob)
-        if world > 1:
-            ba.set_allreduce(sdist.make_allreduce_hook())
+        attach(ba)
         ba.initialize()
         return ba
 
@@ -518,7 +543,7 @@ def main():
                    "parallelism": "landmark-shard x%d" % world,
                    "chol_tile": int(hs.chol_tile), "reduced_n": int(hs.chol_n), "reduced_tiles": int(hs.chol_tiles_nnz),
                    "trials_per_iteration": head["trials"], "final_chi2_plain": head["chi"][0], "final_chi2_robust": head["chi"][1],
-                   "allreduce_doubles_per_trial": int(hs.reduce_doubles) if world > 1 else 0,
+                   "allreduce_doubles_per_trial": int(hs.reduce_doubles) if world > 1 else 0, "allreduce_hook": hook_used,
                    "state": "resident in HBM during the timed iterations (SURVEY 8d-i)", "readback_ms_once": head["readback_ms"]},
         "roofline": {"bound": "hbm", "kernel": "Jacobian sweep = k_linearize_lm (K2) + k_linearize_pose (K3)",
                      "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,

@@ -644,6 +644,16 @@ int svi_ba_save_g2o(svi_ba* ba, const char* path);
 typedef int (*svi_allreduce_fn)(void* user, void* buf, size_t count, void* stream);
 int svi_ba_set_allreduce(svi_ba* ba, svi_allreduce_fn fn, void* user);
 
+/* A native hook: RCCL (ncclAllReduce, ncclDouble, ncclSum) on the handle's stream, one process per GPU, no Python in
+ * between.  librccl is resolved from the process like the HIP runtime is (csrc/rccl_hook.cpp).
+ *   rank 0:      svi_rccl_unique_id(id)  and hands the 128 bytes to the other ranks by whatever means the host has
+ *   every rank:  svi_rccl_create(id, rank, n_ranks, device, &c);  svi_ba_set_allreduce(ba, svi_rccl_allreduce, c) */
+typedef struct svi_rccl svi_rccl;
+int svi_rccl_unique_id(void* id_out /* 128 bytes */);
+int svi_rccl_create(const void* unique_id, int rank, int n_ranks, int device, svi_rccl** out);
+int svi_rccl_destroy(svi_rccl* c);
+int svi_rccl_allreduce(void* user /* svi_rccl* */, void* buf, size_t count, void* stream);
+
 /* --- instrumentation ----------------------------------------------------------------------- */
 enum svi_ba_phase {
     SVI_PH_LINEARIZE_LM   = 0, /* K2: landmark-major Jacobian sweep -> N,Z per edge, H_ll, b_l, chi2   */

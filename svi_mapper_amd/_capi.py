@@ -197,6 +197,10 @@ SIGNATURES = {
     "svi_ba_load_g2o": (C.c_int, [vp, C.c_char_p]),
     "svi_ba_save_g2o": (C.c_int, [vp, C.c_char_p]),
     "svi_ba_set_allreduce": (C.c_int, [vp, ALLREDUCE_FN, vp]),
+    "svi_rccl_unique_id": (C.c_int, [vp]),
+    "svi_rccl_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
+    "svi_rccl_destroy": (C.c_int, [vp]),
+    "svi_rccl_allreduce": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "svi_ba_get_phase_times": (C.c_int, [vp, f64p, i64p]),
     "svi_ba_reset_phase_times": (C.c_int, [vp]),
     "svi_ba_get_stats": (C.c_int, [vp, C.POINTER(BaStats)]),

@@ -66,6 +66,45 @@ def make_allreduce_hook(group=None):
     return hook
 
 
+class NativeRccl:
+    """An RCCL communicator owned by libsvi_hot.so (svi_rccl_*): the C++ hook a torchless host would use.  The 128-byte unique
+    id of rank 0 reaches the other ranks through `exchange(id_bytes_or_None) -> id_bytes` (here: torch.distributed's object
+    broadcast, any side channel will do); after that no Python sits between the library and RCCL."""
+
+    def __init__(self, rank, n_ranks, device, exchange=None):
+        import ctypes as C
+
+        from . import _capi
+        lib = _capi.load_library()
+        buf = (C.c_char * 128)()
+        if rank == 0:
+            _capi.check(lib.svi_rccl_unique_id(buf), "svi_rccl_unique_id")
+        raw = bytes(buf)
+        if n_ranks > 1:
+            if exchange is None:
+                import torch.distributed as dist
+                box = [raw if rank == 0 else None]
+                dist.broadcast_object_list(box, src=0)
+                raw = box[0]
+            else:
+                raw = exchange(raw if rank == 0 else None)
+        idb = (C.c_char * 128).from_buffer_copy(raw)
+        h = C.c_void_p()
+        _capi.check(lib.svi_rccl_create(idb, int(rank), int(n_ranks), int(device), C.byref(h)), "svi_rccl_create")
+        self._lib, self.handle = lib, h
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.svi_rccl_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def init_from_env(backend="nccl"):
     """torchrun-style init: RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* from the environment."""
     import os

@@ -249,6 +249,12 @@ class BundleAdjuster:
         self._hook = _capi.ALLREDUCE_FN(tramp)
         check(self._lib.svi_ba_set_allreduce(self._h, self._hook, None), "svi_ba_set_allreduce")
 
+    def set_allreduce_native(self, comm):
+        """the library's own RCCL hook (csrc/rccl_hook.cpp): comm = svi_mapper_amd.dist.NativeRccl; no Python on the data path"""
+        self._hook = comm           # keeps the communicator alive
+        fn = C.cast(self._lib.svi_rccl_allreduce, _capi.ALLREDUCE_FN)
+        check(self._lib.svi_ba_set_allreduce(self._h, fn, comm.handle), "svi_ba_set_allreduce")
+
     def stats(self):
         s = BaStats()
         check(self._lib.svi_ba_get_stats(self._h, C.byref(s)), "svi_ba_get_stats")

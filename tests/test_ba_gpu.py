@@ -455,8 +455,8 @@ def test_c4_first_iterations_parity(svi, oracle):
 
 def test_c4_properties(svi):
     """BASELINE config 4 (500 KF / 100 k landmarks / 800 k edges), size-independent properties:
-    accepted LM steps never increase the robust chi2, the result is reproducible run to run, and a
-    2-way landmark-sharded solve (hook summing the two shards' buffers) equals the unsharded one."""
+    accepted LM steps never increase the robust chi2 and the result is reproducible run to run (the 2-way landmark-sharded
+    solve at this size is tests/test_dist_gpu.py::test_c4_two_shards_equal_unsharded)."""
     prob = synth.make_c4()
     g, sg = _make(svi.BundleAdjuster, prob)
     assert abs(int(sg.sum()) - 800000) < 8000

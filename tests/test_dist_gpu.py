@@ -93,6 +93,28 @@ def test_sharded_equals_unsharded(svi, n_ranks):
         assert abs(o[3][0] - ref.chi2()[0]) <= 1e-9 * ref.chi2()[0]
 
 
+def test_c4_two_shards_equal_unsharded(svi):
+    """BASELINE config 4 at full size (500 key frames / 100 k landmarks / 800 k edges) cut into two landmark shards on one GPU,
+    their reduced systems summed through the hook: the same iterations, the same estimates as the unsharded solve"""
+    prob = synth.make_c4()
+    cam = prob["cam"]
+    iters = (1, 3)
+    ref = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"])
+    synth.build_ba_graph(ref, prob)
+    ref.initialize()
+    done = [ref.optimize(n) for n in iters]
+    T, p = ref.get_poses()[1], ref.get_landmarks()[1]
+    chi = ref.chi2()
+    ref.close()
+    out = _run_sharded(svi, prob, 2, iters)
+    assert sum(o[4] for o in out) == prob["n_lm"] and abs(out[0][4] - out[1][4]) < 0.05 * prob["n_lm"]   # balanced by edge count
+    for o in out:
+        assert o[0] == done
+        assert np.abs(o[1] - T).max() < 1e-9 and np.abs(o[2] - p).max() < 1e-9 * np.abs(p).max()
+        assert abs(o[3][0] - chi[0]) <= 1e-9 * chi[0]
+    assert np.array_equal(out[0][1], out[1][1])
+
+
 def test_failed_trial_is_failed_on_every_rank(svi):
     """one landmark block is not positive definite until lambda has grown (a prior with negative information): only the
     rank that owns the landmark sees that in its status word - the failure has to travel with the reduced scalars, or the
