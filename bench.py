@@ -377,7 +377,7 @@ def main():
     ap.add_argument("--no-replay", action="store_true", help="skip the back-to-back sweep replays (rocprof runs: the kernel stats "
                     "then hold in-loop launches only)")
     ap.add_argument("--cpu-iters", type=int, default=30)
-    ap.add_argument("--chol-tile", type=int, default=96)
+    ap.add_argument("--chol-tile", type=int, default=48)
     ap.add_argument("--backend", default="nccl")
     ap.add_argument("--hook", choices=("native", "torch"), default="native",
                     help="N > 1: the all-reduce of the reduced system through the library's own RCCL communicator (C++, svi_rccl_*) or "

@@ -521,7 +521,8 @@ typedef struct svi_ba_options {
     int    n_ranks;
     /* record hipEvents around every phase (svi_ba_get_phase_times) */
     int    profile;
-    /* reduced camera system tile edge (multiple of 48; 0 = default 96) */
+    /* reduced camera system tile edge (48 or 96; 0 = default 48: shorter pivot chains per dependency level - measured faster on
+     * configs 3, 4 and 5 although the levels double) */
     int    chol_tile;
     /* elimination order of the reduced camera system: 0 = nested dissection of the key-frame sequence (independent
      * chains factorised side by side), 1 = natural (ascending id: one chain) */

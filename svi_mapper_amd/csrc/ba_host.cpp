@@ -443,7 +443,7 @@ void svi_ba_options_default(svi_ba_options* o)
     o->lm_tau = 1e-5; o->lm_good_step_lower = 1.0 / 3.0; o->lm_good_step_upper = 2.0 / 3.0; o->lm_max_trials = 10;
     o->max_depth_xyz_l2 = 10.0; o->max_depth_uvdepth_l2 = 50.0; o->max_depth_uvdisp_l2 = 10000.0; o->sane_position_l2 = 1e12;
     o->n_ranks = 1;
-    o->chol_tile = 96;
+    o->chol_tile = 48;
     o->chol_order = 0;
 }
 
@@ -456,7 +456,7 @@ int svi_ba_create(const svi_ba_options* o, svi_ba** out)
     if (int rc = use_device(o->device)) return rc;
     svi_ba* ba = new svi_ba();
     ba->opt = *o;
-    if (ba->opt.chol_tile == 0) ba->opt.chol_tile = 96;
+    if (ba->opt.chol_tile == 0) ba->opt.chol_tile = 48;
     if (o->stream) ba->stream = static_cast<hipStream_t>(o->stream);
     else {
         hipError_t e = hipStreamCreateWithFlags(&ba->stream, hipStreamNonBlocking);

@@ -228,7 +228,7 @@ void elimination_order(Build& b)
     const int Pf = b.Pf;
     ba->red_perm.resize(Pf);
     std::iota(ba->red_perm.begin(), ba->red_perm.end(), 0);
-    const int TSo = o.chol_tile > 0 ? o.chol_tile : 96;
+    const int TSo = o.chol_tile > 0 ? o.chol_tile : 48;
     const int PBo = TSo / 6;
     const int NTo = PBo > 0 ? (Pf + PBo - 1) / PBo : 0;
     if (!(o.chol_order == 0 && PBo > 0 && NTo >= 6)) return;
@@ -482,7 +482,7 @@ int tile_structure(Build& b)
 {
     svi_ba* ba = b.ba;
     const svi_ba_options& o = ba->opt;
-    b.TS = o.chol_tile > 0 ? o.chol_tile : 96;
+    b.TS = o.chol_tile > 0 ? o.chol_tile : 48;
     if (b.TS % 48 != 0 || b.TS > kMaxTile) return fail(SVI_ERR_INVALID, "chol_tile must be 48 or 96");
     const int TS = b.TS, PB = TS / 6;
     b.PB = PB;

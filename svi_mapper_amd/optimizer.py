@@ -30,7 +30,7 @@ class BundleAdjuster:
     """LM bundle adjustment with the reference's graph rules, on one MI355X (or one shard of a node)."""
 
     def __init__(self, fx, fy, cx, cy, baseline_m, device=0, stream=None, rank=0, n_ranks=1, profile=False,
-                 chol_tile=96, sweep_events=False, **lm):
+                 chol_tile=48, sweep_events=False, **lm):
         self._lib = _capi.load_library()
         o = BaOptions()
         self._lib.svi_ba_options_default(C.byref(o))
