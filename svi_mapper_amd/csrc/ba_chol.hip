@@ -132,6 +132,28 @@ __device__ __forceinline__ double fast_rsqrt(double x)
 
 constexpr int kPotrfThreads = 512;
 
+// Tile edge 48: the triangular solves of a level (L_ik = S_ik L_kk^-T) are not a launch of their own - every consumer of
+// L_ik in the NEXT level's launch (the chain workgroup that applies it to its diagonal tile, the grouped updates) forms it
+// on the spot from S_ik and L_kk^-1 (a 48^3 product: 27 matrix-core steps), and the one that owns the diagonal target of
+// row i also stores it for the backward substitution.  One launch per dependency level instead of two; with 96-wide tiles
+// the three LDS images this needs do not fit beside the factorisation's own (k_trsm stays).
+template <int TS> struct Fold { static constexpr bool on = TS == 48; };
+
+// the 16x16 accumulator block `acc` (row (lane>>4) + 4q, column lane&15) into an LDS image at (r0, c0)
+template <int LD> __device__ __forceinline__ void block_to_lds(const v4f64& acc, double* s, int r0, int c0)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) s[(r0 + (lane >> 4) + 4 * q) * LD + c0 + (lane & 15)] = acc[q];
+}
+// ... and into a row-major global tile
+template <int TS> __device__ __forceinline__ void block_to_global(const v4f64& acc, double* __restrict__ g, int r0, int c0)
+{
+    const int lane = threadIdx.x & 63;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) g[(size_t)(r0 + (lane >> 4) + 4 * q) * TS + c0 + (lane & 15)] = acc[q];
+}
+
 // ---------------------------------------------------------------------------------------------
 // potrf + inverse + y_k of one diagonal tile, 512 threads.  The right-looking sweep eliminates FOUR columns per
 // barrier (the 4x4 pivot block is factorised redundantly by every lane) and keeps the tile in MFMA accumulator
@@ -145,8 +167,9 @@ constexpr int kPotrfThreads = 512;
 template <int TS>
 __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, double* __restrict__ Lg, double* sL, double* sX,
                                                  double (*s_col)[TS][4], double* s_rs, int k, int n, double lambda, int stop_after,
-                                                 double* __restrict__ y, const double* __restrict__ Lt, const int* __restrict__ pre_tile,
-                                                 const int* __restrict__ pre_col, int npre, double* s_g)
+                                                 double* __restrict__ y, double* __restrict__ Lt, const int* __restrict__ pre_tile,
+                                                 const int* __restrict__ pre_col, int npre, double* s_g, const double* __restrict__ S_all,
+                                                 const double* __restrict__ Linv_all, double* sT)
 {
     constexpr int NB = TS / 16, LD = Lds<TS>::LD, KB = 4;
     constexpr int NBLK = NB * (NB + 1) / 2, NWV = kPotrfThreads / 64, PER = (NBLK + NWV - 1) / NWV;
@@ -182,12 +205,57 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
     // pending updates of this tile from the columns of the level just below: A -= L(k,q) L(k,q)' and the forward
     // substitution g_k -= L(k,q) y_q, done here so the critical path is one launch per level.  L(k,q) is staged in
     // the (still unused) L image, y_q in s_rs.
-    TileRegs<TS> pre;
-    double ypre = 0.0;
-    if (npre > 0) { tile_load<TS>(Lt + (size_t)pre_tile[0] * TS * TS, pre); if (tid < TS) ypre = y[pre_col[0] * TS + tid]; }
     v4f64 accU[PER];
 #pragma unroll
     for (int u = 0; u < PER; ++u) accU[u] = {0.0, 0.0, 0.0, 0.0};
+    if constexpr (Fold<TS>::on) {
+        // L(k,q) = S(k,q) L_qq^-T is formed here (no k_trsm launch): S(k,q) -> sX, L_qq^-1 -> sL, the product -> sT and, for
+        // the backward substitution, to its tile of Lt
+        TileRegs<TS> ps, px;
+        double ypre = 0.0;
+        if (npre > 0) {
+            tile_load<TS>(S_all + (size_t)pre_tile[0] * TS * TS, ps);
+            tile_load<TS>(Linv_all + (size_t)pre_col[0] * TS * TS, px);
+            if (tid < TS) ypre = y[pre_col[0] * TS + tid];
+        }
+        for (int w = 0; w < npre; ++w) {
+            tile_store<TS>(ps, sX);
+            tile_store<TS>(px, sL);
+            if (tid < TS) s_rs[tid] = ypre;
+            __syncthreads();
+            double* Lout = Lt + (size_t)pre_tile[w] * TS * TS;
+            if (w + 1 < npre) { // the next source travels while this one is multiplied
+                tile_load<TS>(S_all + (size_t)pre_tile[w + 1] * TS * TS, ps);
+                tile_load<TS>(Linv_all + (size_t)pre_col[w + 1] * TS * TS, px);
+                if (tid < TS) ypre = y[pre_col[w + 1] * TS + tid];
+            }
+            for (int st = wave; st < NB * NB; st += NWV) {
+                const int r0 = (st / NB) * 16, c0 = (st % NB) * 16;
+                const v4f64 lb = mfma_block<TS, LD>(sX, r0, sL, c0);
+                block_to_lds<LD>(lb, sT, r0, c0);
+                block_to_global<TS>(lb, Lout, r0, c0);
+            }
+            __syncthreads();
+#pragma unroll
+            for (int u = 0; u < PER; ++u)
+                if (own[u]) accU[u] = mfma_block_acc<TS, LD>(sT, 16 * ba[u], sT, 16 * bb[u], accU[u]);
+            if (tid < TS) {
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 6
+                for (int m = 0; m < TS; m += 4) {
+                    a0 = fma(sT[tid * LD + m], s_rs[m], a0);
+                    a1 = fma(sT[tid * LD + m + 1], s_rs[m + 1], a1);
+                    a2 = fma(sT[tid * LD + m + 2], s_rs[m + 2], a2);
+                    a3 = fma(sT[tid * LD + m + 3], s_rs[m + 3], a3);
+                }
+                s_g[tid] -= (a0 + a1) + (a2 + a3);
+            }
+            __syncthreads();
+        }
+    } else {
+    TileRegs<TS> pre;
+    double ypre = 0.0;
+    if (npre > 0) { tile_load<TS>(Lt + (size_t)pre_tile[0] * TS * TS, pre); if (tid < TS) ypre = y[pre_col[0] * TS + tid]; }
     for (int w = 0; w < npre; ++w) {
         tile_store<TS>(pre, sL);
         if (tid < TS) s_rs[tid] = ypre;
@@ -209,6 +277,7 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
             s_g[tid] -= (a0 + a1) + (a2 + a3);
         }
         __syncthreads();
+    }
     }
 #pragma unroll
     for (int u = 0; u < PER; ++u)
@@ -330,8 +399,8 @@ struct StepArgs {
 };
 
 template <int TS>
-__device__ void gemm_target_block(double* __restrict__ S, const double* __restrict__ Lt, const StepArgs& sa, int work, double* __restrict__ g,
-                                  const double* __restrict__ y, double* sm);
+__device__ void gemm_target_block(double* __restrict__ S, double* __restrict__ Lt, const double* __restrict__ Linv, const StepArgs& sa, int work,
+                                  double* __restrict__ g, const double* __restrict__ y, double* sm);
 
 // One dependency level of the factorisation.  Workgroups 0..n_chain-1 are the critical path: each applies the
 // pending updates of its diagonal tile from the level just below, then factorises it (potrf + inverse + y_k).
@@ -357,12 +426,13 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
     const int failed = *status; // tested together with the column record: one round trip, not two
     const int4 ds = sa.chain_desc[2 * ((int)blockIdx.x < sa.n_chain ? (int)blockIdx.x : 0)];
     if (failed != 0) return;
-    if ((int)blockIdx.x >= sa.n_chain) { gemm_target_block<TS>(S, Lt, sa, (int)blockIdx.x - sa.n_chain, g, y, sm); return; }
+    if ((int)blockIdx.x >= sa.n_chain) { gemm_target_block<TS>(S, Lt, Linv, sa, (int)blockIdx.x - sa.n_chain, g, y, sm); return; }
     const int k = ds.x, tile_id = ds.y, pre0 = ds.z, npre = ds.w;
     const double* A = S + (size_t)tile_id * TS * TS;
     double* Lg = Lt + (size_t)tile_id * TS * TS;
     if (tid < TS) s_g[tid] = g[k * TS + tid];
-    const bool ok = potrf_sweep_mfma<TS>(A, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y, Lt, sa.pre_tile + pre0, sa.pre_col + pre0, npre, s_g);
+    const bool ok = potrf_sweep_mfma<TS>(A, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y, Lt, sa.pre_tile + pre0, sa.pre_col + pre0, npre, s_g, S,
+                                         Linv, sm + 2 * TS * LD);
     if (!ok) { if (tid == 0) *status = k + 1; return; }
     if (stop_after == 5 || (stop_after >= 6 && stop_after <= 9) || stop_after == 1) return;
     __syncthreads();
@@ -499,9 +569,86 @@ __global__ __launch_bounds__(kBlock) void k_trsm(const double* __restrict__ S, d
 // ---------------------------------------------------------------------------------------------
 
 template <int TS>
-__device__ void gemm_target_block(double* __restrict__ S, const double* __restrict__ Lt, const StepArgs& sa, int work, double* __restrict__ g,
-                                  const double* __restrict__ y, double* sm)
+__device__ void gemm_target_block(double* __restrict__ S, double* __restrict__ Lt, const double* __restrict__ Linv, const StepArgs& sa, int work,
+                                  double* __restrict__ g, const double* __restrict__ y, double* sm)
 {
+    if constexpr (Fold<TS>::on) {
+        // tile edge 48 = one output block per target: the operand tiles L(i,q), L(j,q) are formed here from S and L_qq^-1
+        // (no k_trsm launch); the diagonal target of row i stores L(i,q) for the backward substitution
+        constexpr int LD = Lds<TS>::LD, NB = TS / 16;
+        static_assert(TS == kOB, "one 48 x 48 block per target tile");
+        double* sSa = sm;
+        double* sSb = sm + TS * LD;
+        double* sXq = sm + 2 * TS * LD;
+        double* sLa = sm + 3 * TS * LD;
+        double* sLb = sm + 4 * TS * LD;
+        const int t = work;
+        const int p0 = sa.tgt_pair_ptr[t], p1 = sa.tgt_pair_ptr[t + 1];
+        const int row = sa.tgt_row[t];
+        const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        constexpr int NWV = kPotrfThreads / 64;
+        v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        double gacc = 0.0;
+        const bool g_thread = row >= 0 && threadIdx.x >= 64 && threadIdx.x < 64 + TS;
+        TileRegs<TS> ra, rb, rx;
+        auto fetch = [&](int q) {
+            tile_load<TS>(S + (size_t)sa.pair_a[q] * TS * TS, ra);
+            if (sa.pair_b[q] != sa.pair_a[q]) tile_load<TS>(S + (size_t)sa.pair_b[q] * TS * TS, rb);
+            tile_load<TS>(Linv + (size_t)sa.pair_src[q] * TS * TS, rx);
+        };
+        if (p0 < p1) fetch(p0);
+        for (int q = p0; q < p1; ++q) {
+            const bool same = sa.pair_a[q] == sa.pair_b[q]; // uniform
+            tile_store<TS>(ra, sSa);
+            if (!same) tile_store<TS>(rb, sSb);
+            tile_store<TS>(rx, sXq);
+            __syncthreads();
+            double* Lout = Lt + (size_t)sa.pair_a[q] * TS * TS;
+            const double* yq = y + sa.pair_src[q] * TS;
+            if (q + 1 < p1) fetch(q + 1);
+            for (int st = wave; st < (same ? 1 : 2) * NB * NB; st += NWV) {
+                const int which = st / (NB * NB), bq = st % (NB * NB), r0 = (bq / NB) * 16, c0 = (bq % NB) * 16;
+                const v4f64 lb = mfma_block<TS, LD>(which ? sSb : sSa, r0, sXq, c0);
+                block_to_lds<LD>(lb, which ? sLb : sLa, r0, c0);
+                if (same) block_to_global<TS>(lb, Lout, r0, c0); // the diagonal target of row i owns L(i,q)
+            }
+            __syncthreads();
+            const double* pa = sLa;
+            const double* pb = same ? sLa : sLb;
+            {
+                const int st0 = wave, st1 = wave + NWV;
+                acc0 = mfma_block_acc<TS, LD>(pa, (st0 / 3) * 16, pb, (st0 % 3) * 16, acc0);
+                if (st1 < 9) acc1 = mfma_block_acc<TS, LD>(pa, (st1 / 3) * 16, pb, (st1 % 3) * 16, acc1);
+            }
+            if (g_thread) { // forward substitution rides along: g_i -= L_iq y_q
+                const int r = threadIdx.x - 64;
+                double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll 6
+                for (int m = 0; m < TS; m += 4) {
+                    a0 = fma(sLa[r * LD + m], yq[m], a0);
+                    a1 = fma(sLa[r * LD + m + 1], yq[m + 1], a1);
+                    a2 = fma(sLa[r * LD + m + 2], yq[m + 2], a2);
+                    a3 = fma(sLa[r * LD + m + 3], yq[m + 3], a3);
+                }
+                gacc += (a0 + a1) + (a2 + a3);
+            }
+            __syncthreads();
+        }
+        double* C = S + (size_t)sa.tgt_tile[t] * TS * TS;
+        {
+            const int st0 = wave, st1 = wave + NWV;
+            const int r0 = (st0 / 3) * 16, c0 = (st0 % 3) * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) C[(size_t)(r0 + (lane >> 4) + 4 * q) * TS + c0 + (lane & 15)] -= acc0[q];
+            if (st1 < 9) {
+                const int r1 = (st1 / 3) * 16, c1 = (st1 % 3) * 16;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) C[(size_t)(r1 + (lane >> 4) + 4 * q) * TS + c1 + (lane & 15)] -= acc1[q];
+            }
+        }
+        if (g_thread) g[row * TS + (threadIdx.x - 64)] -= gacc;
+        return;
+    } else {
     constexpr int LD = Lds<TS>::LD, Q = TS / kOB;
     double* sA = sm;
     double* sB = sm + kOB * LD;
@@ -570,6 +717,7 @@ __device__ void gemm_target_block(double* __restrict__ S, const double* __restri
         for (int q = 0; q < 4; ++q) C[(size_t)(kOB * qr + r0 + (lane >> 4) + 4 * q) * TS + kOB * qc + c0 + (lane & 15)] -= acc1[q];
     }
     if (g_thread) g[row * TS + kOB * qr + (threadIdx.x - 64)] -= gacc;
+    }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -664,7 +812,7 @@ template <int TS>
 int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n, int* status, hipStream_t s)
 {
     constexpr int LD = Lds<TS>::LD, Q = TS / kOB;
-    const size_t lds_p = sizeof(double) * 2 * (size_t)TS * LD;
+    const size_t lds_p = sizeof(double) * (Fold<TS>::on ? 5 : 2) * (size_t)TS * LD; // folded: the grouped updates stage five images
     constexpr int kTB = TrsmBlock<TS>::TB, QT = TS / kTB;
     const size_t lds_g = sizeof(double) * 2 * (size_t)kTB * LD;
     static bool attr = false;
@@ -686,7 +834,7 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
         sa.tgt_tile = p.tgt_tile + t0; sa.tgt_row = p.tgt_row + t0; sa.tgt_pair_ptr = p.tgt_pair_ptr + t0;
         hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(nc + ntg * Q * Q), dim3(kPotrfThreads), lds_p, s, S, Lt, Linv, g, x, n, lambda, status, 0, sa);
         const int i0 = p.h_trsm_ptr[st], ni = p.h_trsm_ptr[st + 1] - i0;
-        if (ni > 0) hipLaunchKernelGGL(k_trsm<TS>, dim3(ni * QT * QT), dim3(kBlock), lds_g, s, S, Lt, Linv, p.st_tile + i0, p.st_col + i0, status);
+        if (ni > 0 && !Fold<TS>::on) hipLaunchKernelGGL(k_trsm<TS>, dim3(ni * QT * QT), dim3(kBlock), lds_g, s, S, Lt, Linv, p.st_tile + i0, p.st_col + i0, status);
     }
     for (int st = p.n_steps - 2; st >= 0; --st) { // (the last level solved its x inside k_potrf_inv)
         const int c0 = p.h_step_ptr[st], nc = p.h_step_ptr[st + 1] - c0;
@@ -703,7 +851,7 @@ template <int TS>
 static int potrf_probe(int reps, int stop_after, double* ms_out)
 {
     constexpr int LD = Lds<TS>::LD;
-    const size_t lds_p = sizeof(double) * 2 * (size_t)TS * LD;
+    const size_t lds_p = sizeof(double) * (Fold<TS>::on ? 5 : 2) * (size_t)TS * LD;
     if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv<TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p) != hipSuccess) return 1;
     double *S = nullptr, *L = nullptr, *X = nullptr, *g = nullptr, *y = nullptr;
     int *st = nullptr, *tab = nullptr; // tab: an all-zero column record (column 0, tile 0, nothing pending)
