@@ -16,7 +16,7 @@ from collections import defaultdict
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 KERNELS = ["k_linearize_lm", "k_linearize_pose", "k_schur", "k_assemble", "k_backsub_chi2<true, true>", "k_potrf_inv", "k_trsm", "k_back_solve",
-           "k_match_hamming256"]
+           "k_match_hamming256", "k_match_rowbucket", "k_gather_edges"]
 
 
 def per_kernel(path):
@@ -45,7 +45,8 @@ def main(d):
     out = {
         "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in separate passes (MI355X_MICROARCH.md HBM section); counters are in KiB; "
                   "both are calibrated on 1 GiB coalesced 8 B/lane streaming kernels (tools/pmc_calib.hip): FETCH_SIZE reports ~1/2 of the bytes "
-                  "on gfx950, WRITE_SIZE is exact; values are bytes per launch averaged over every launch of `bench.py --steps 10` at config 4",
+                  "on gfx950, WRITE_SIZE is exact; values are bytes per launch averaged over every launch of `bench.py --steps 10 --no-replay` at config 4 "
+                  "(all launches inside LM loops); these are bytes at the L2 <-> fabric boundary: Infinity-Cache hits are in them",
         "source": os.path.relpath(d, ROOT),
         "fetch_correction": fetch_corr,
         "write_correction": write_corr,
