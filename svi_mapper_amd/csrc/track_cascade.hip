@@ -37,6 +37,7 @@ struct svi_tracker {
     svi_track_landmarks lm{};
     bool planned = false;
     int64_t total_samples = 0;
+    int64_t n_no_motion = 0;       // landmarks of the frame whose detection point has not moved (stage 2 stands in for stage 3)
     // workspace: one growable device buffer per role
     enum { kRecords, kS3Seg, kMaskA, kMaskB, kMaskC, kMaskFound, kMaskRun, kUvRef, kTopLeft, kOk, kRoi, kRoiI, kSegIn, kKpIn, kSegE, kKpE, kDescE, kIdx,
            kDist, kStatus, kDescHere, kSegR, kStRange, kRoi2, kPoolUv, kSeg2, kPoolUv2, kPool, kIdx2, kDist2, kStatus2, kUvOther, kXyz, kDescOther,
@@ -70,6 +71,21 @@ __global__ __launch_bounds__(kB) void k_mask(const svi_track_record* __restrict_
     bool v = mode == kMaskFovBoth ? fov : mode == kMaskEpiOk ? (st & SVI_TRK_EPI_OK) != 0 : (fov && (st & SVI_TRK_EPI_NO_MOTION));
     if (active && !active[i]) v = false;
     out[i] = v ? 1 : 0;
+}
+
+// how many landmarks are inside both fields of view but have no epipolar line (their detection point did not move): counted
+// with the plan so that trackEpipolar knows without asking the device again whether its stage-2 branch has anything to do
+__global__ __launch_bounds__(kB) void k_count_no_motion(const svi_track_record* __restrict__ rec, int n, const int32_t* __restrict__ seg, int32_t* __restrict__ out)
+{
+    const int i = blockIdx.x * kB + threadIdx.x;
+    int hit = 0;
+    if (i < n) {
+        const int st = rec[i].status;
+        hit = ((st & SVI_TRK_FOV_LEFT) && (st & SVI_TRK_FOV_RIGHT) && (st & SVI_TRK_EPI_NO_MOTION)) ? 1 : 0;
+    }
+    const unsigned long long m = __ballot(hit);
+    if ((threadIdx.x & 63) == 0 && m) atomicAdd(out + 1, (int32_t)__popcll(m));
+    if (i == 0) out[0] = seg[n];
 }
 
 // rows of `run` whose status is not OK: what the next stage of trackManual takes over
@@ -617,11 +633,19 @@ int svi_tracker_plan(svi_tracker* t, const double* T_world_to_left, const double
     SVI_HIP(hipSetDevice(t->m->device));
     SVI_TRY(t->take(svi_tracker::kRecords, (size_t)lm->n, &rec));
     SVI_TRY(t->take(svi_tracker::kS3Seg, (size_t)lm->n + 1, &seg));
-    int64_t total = 0;
     SVI_TRY(svi_track_plan_dev(t->m, &t->cam, T_world_to_left, dp_T_left_to_world, n_dp, motion_scaling, lm->xyz_world, lm->kp_size, lm->last_disparity,
-                               lm->uv_reference, lm->dp_index, lm->n, rec, seg, &total));
+                               lm->uv_reference, lm->dp_index, lm->n, rec, seg, nullptr));
+    // one wait for both numbers the host needs: the samples of the frame and the landmarks without an epipolar line
+    int32_t* cnt = nullptr;
+    SVI_TRY(t->take(svi_tracker::kIdx2, 2, &cnt));
+    SVI_HIP(hipMemsetAsync(cnt, 0, 2 * sizeof(int32_t), t->m->stream));
+    hipLaunchKernelGGL(k_count_no_motion, grid_for(std::max(lm->n, 1)), dim3(kB), 0, t->m->stream, rec, lm->n, seg, cnt);
+    int32_t h[2] = {0, 0};
+    SVI_HIP(hipMemcpyAsync(h, cnt, sizeof(h), hipMemcpyDeviceToHost, t->m->stream));
+    SVI_HIP(hipStreamSynchronize(t->m->stream));
     t->lm = *lm;
-    t->total_samples = total;
+    t->total_samples = h[0];
+    t->n_no_motion = h[1];
     t->planned = true;
     return SVI_OK;
 }
@@ -677,7 +701,7 @@ int svi_track_epipolar(svi_tracker* t, const uint8_t* active, const svi_track_re
     SVI_TRY(make_mask(t, active, kMaskEpiOk, svi_tracker::kMaskC, &run));
     SVI_TRY(run_stage3(t, run, out));
     // a detection point that has not moved has no epipolar line (:847): its landmarks are searched by stage 2 (:1026-1290)
-    if (t->det) {
+    if (t->det && t->n_no_motion > 0) {
         SVI_TRY(make_mask(t, active, kMaskNoMotionFov, svi_tracker::kMaskC, &run));
         SVI_TRY(run_stage2(t, run, out, nullptr));
     }
