@@ -165,12 +165,19 @@ template <int TS> __device__ __forceinline__ void block_to_global(const v4f64& a
 // out of an update by zeroing the operand, so an accumulator column always ends as the unscaled factor column.
 // ---------------------------------------------------------------------------------------------
 template <int TS>
-__device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, double* __restrict__ Lg, double* sL, double* sX,
+__device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, double* __restrict__ Lg, double* sL, double* sX,
                                                  double (*s_col)[TS][4], double* s_rs, int k, int n, double lambda, int stop_after,
-                                                 double* __restrict__ y, double* __restrict__ Lt, const int* __restrict__ pre_tile,
-                                                 const int* __restrict__ pre_col, int npre, double* s_g, const double* __restrict__ S_all,
-                                                 const double* __restrict__ Linv_all, double* sT)
+                                                 double* __restrict__ y, double* __restrict__ Lt, const int* __restrict__ pre_tile_g,
+                                                 const int* __restrict__ pre_col_g, int npre, double* s_g, const double* __restrict__ S_all,
+                                                 const double* __restrict__ Linv_all, double* sT, const int* __restrict__ status,
+                                                 bool use_inl, int it0, int it1, int ic0, int ic1)
 {
+    // the status word goes first, the operand tiles right behind it: the test waits for its own load only
+    const int failed_before = *status;
+    static_assert(kInlinePre == 2, "the inline record is selected without indexing");
+    auto pre_tile = [=](int w) { return use_inl ? (w == 0 ? it0 : it1) : pre_tile_g[w]; };
+    auto pre_col = [=](int w) { return use_inl ? (w == 0 ? ic0 : ic1) : pre_col_g[w]; };
+    constexpr int kOk = 0, kNotPositive = 1, kAborted = 2;
     constexpr int NB = TS / 16, LD = Lds<TS>::LD, KB = 4;
     constexpr int NBLK = NB * (NB + 1) / 2, NWV = kPotrfThreads / 64, PER = (NBLK + NWV - 1) / NWV;
     static_assert(kPotrfThreads == 512, "TileRegs assumes 512 threads");
@@ -214,20 +221,21 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
         TileRegs<TS> ps, px;
         double ypre = 0.0;
         if (npre > 0) {
-            tile_load<TS>(S_all + (size_t)pre_tile[0] * TS * TS, ps);
-            tile_load<TS>(Linv_all + (size_t)pre_col[0] * TS * TS, px);
-            if (tid < TS) ypre = y[pre_col[0] * TS + tid];
+            tile_load<TS>(S_all + (size_t)pre_tile(0) * TS * TS, ps);
+            tile_load<TS>(Linv_all + (size_t)pre_col(0) * TS * TS, px);
+            if (tid < TS) ypre = y[pre_col(0) * TS + tid];
         }
+        if (failed_before != 0) return kAborted; // an earlier column failed: nothing more to do in this trial
         for (int w = 0; w < npre; ++w) {
             tile_store<TS>(ps, sX);
             tile_store<TS>(px, sL);
             if (tid < TS) s_rs[tid] = ypre;
             __syncthreads();
-            double* Lout = Lt + (size_t)pre_tile[w] * TS * TS;
+            double* Lout = Lt + (size_t)pre_tile(w) * TS * TS;
             if (w + 1 < npre) { // the next source travels while this one is multiplied
-                tile_load<TS>(S_all + (size_t)pre_tile[w + 1] * TS * TS, ps);
-                tile_load<TS>(Linv_all + (size_t)pre_col[w + 1] * TS * TS, px);
-                if (tid < TS) ypre = y[pre_col[w + 1] * TS + tid];
+                tile_load<TS>(S_all + (size_t)pre_tile(w + 1) * TS * TS, ps);
+                tile_load<TS>(Linv_all + (size_t)pre_col(w + 1) * TS * TS, px);
+                if (tid < TS) ypre = y[pre_col(w + 1) * TS + tid];
             }
             for (int st = wave; st < NB * NB; st += NWV) {
                 const int r0 = (st / NB) * 16, c0 = (st % NB) * 16;
@@ -255,13 +263,14 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
     } else {
     TileRegs<TS> pre;
     double ypre = 0.0;
-    if (npre > 0) { tile_load<TS>(Lt + (size_t)pre_tile[0] * TS * TS, pre); if (tid < TS) ypre = y[pre_col[0] * TS + tid]; }
+    if (npre > 0) { tile_load<TS>(Lt + (size_t)pre_tile(0) * TS * TS, pre); if (tid < TS) ypre = y[pre_col(0) * TS + tid]; }
+    if (failed_before != 0) return kAborted;
     for (int w = 0; w < npre; ++w) {
         tile_store<TS>(pre, sL);
         if (tid < TS) s_rs[tid] = ypre;
         __syncthreads();
         // the next source tile travels while this one is applied
-        if (w + 1 < npre) { tile_load<TS>(Lt + (size_t)pre_tile[w + 1] * TS * TS, pre); if (tid < TS) ypre = y[pre_col[w + 1] * TS + tid]; }
+        if (w + 1 < npre) { tile_load<TS>(Lt + (size_t)pre_tile(w + 1) * TS * TS, pre); if (tid < TS) ypre = y[pre_col(w + 1) * TS + tid]; }
 #pragma unroll
         for (int u = 0; u < PER; ++u)
             if (own[u]) accU[u] = mfma_block_acc<TS, LD>(sL, 16 * ba[u], sL, 16 * bb[u], accU[u]);
@@ -283,7 +292,7 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
     for (int u = 0; u < PER; ++u)
 #pragma unroll
         for (int q = 0; q < 4; ++q) acc[u][q] -= accU[u][q];
-    if (stop_after == 5) { if (tid < TS) y[k * TS + tid] = acc[0][0]; return true; }
+    if (stop_after == 5) { if (tid < TS) y[k * TS + tid] = acc[0][0]; return kOk; }
     long long t_clk0 = 0, t_rt0 = 0;
     const bool probe = stop_after >= 6 && stop_after <= 9;
     if (probe) { t_clk0 = clock64(); t_rt0 = wall_clock64(); }
@@ -356,12 +365,12 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
         if (fail) break;
     }
     __syncthreads();
-    if (fail) return false;
+    if (fail) return kNotPositive;
     if (probe) { // shader cycles and 100 MHz ticks spent in the pivot sweep
         if (tid == 0) { y[0] = (double)(clock64() - t_clk0); y[1] = (double)(wall_clock64() - t_rt0); y[2] = acc[0][0]; }
-        return true;
+        return kOk;
     }
-    if (stop_after == 1) { if (tid < TS) y[k * TS + tid] = acc[0][0]; return true; }
+    if (stop_after == 1) { if (tid < TS) y[k * TS + tid] = acc[0][0]; return kOk; }
     if (tid < TS) s_rs[tid] = fast_rsqrt(s_rs[tid]);
     for (int i = tid; i < TS * LD; i += kPotrfThreads) sX[i] = 0.0; // X is read whole (y_k, the store): zero above the diagonal
     __syncthreads();
@@ -377,7 +386,7 @@ __device__ __forceinline__ bool potrf_sweep_mfma(const double* __restrict__ A, d
                 if (c <= r) sL[r * LD + c] = acc[u][q] * s_rs[c];
             }
         }
-    return true;
+    return kOk;
 }
 
 // one 48x48 block of S(c) -= L(a) L(b)' by a 512-thread workgroup (defined below)
@@ -396,6 +405,7 @@ struct StepArgs {
     const int* pair_a;
     const int* pair_b;
     const int* pair_src;
+    ChainInline inl;             // the chain workgroups' records, if the level fits
 };
 
 template <int TS>
@@ -423,17 +433,27 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
     static_assert(sizeof(double) * (2 * TS * LD + kScratch + 2 * TS) <= 160 * 1024, "potrf LDS budget (160 KiB per workgroup)");
     double (*s_col)[TS][4] = reinterpret_cast<double (*)[TS][4]>(s_buf);
     const int tid = threadIdx.x;
-    const int failed = *status; // tested together with the column record: one round trip, not two
-    const int4 ds = sa.chain_desc[2 * ((int)blockIdx.x < sa.n_chain ? (int)blockIdx.x : 0)];
-    if (failed != 0) return;
-    if ((int)blockIdx.x >= sa.n_chain) { gemm_target_block<TS>(S, Lt, Linv, sa, (int)blockIdx.x - sa.n_chain, g, y, sm); return; }
-    const int k = ds.x, tile_id = ds.y, pre0 = ds.z, npre = ds.w;
+    if ((int)blockIdx.x >= sa.n_chain) {
+        if (*status != 0) return;
+        gemm_target_block<TS>(S, Lt, Linv, sa, (int)blockIdx.x - sa.n_chain, g, y, sm);
+        return;
+    }
+    // the column record: out of the kernel arguments when the level fits there (no index load in front of the tile loads),
+    // else one 16-byte record; the status word is tested inside the sweep, behind the operand loads it must not delay
+    const bool inl = sa.inl.n > 0;
+    int k, tile_id, pre0 = 0, npre;
+    ChainRec rec = sa.inl.c[0]; // (selected with constant indices: indexing the argument would move it to scratch memory)
+#pragma unroll
+    for (int i = 1; i < kInlineCols; ++i) if ((int)blockIdx.x == i) rec = sa.inl.c[i];
+    if (inl) { k = rec.k; tile_id = rec.tile; npre = rec.npre; }
+    else { const int4 ds = sa.chain_desc[2 * (int)blockIdx.x]; k = ds.x; tile_id = ds.y; pre0 = ds.z; npre = ds.w; }
     const double* A = S + (size_t)tile_id * TS * TS;
     double* Lg = Lt + (size_t)tile_id * TS * TS;
     if (tid < TS) s_g[tid] = g[k * TS + tid];
-    const bool ok = potrf_sweep_mfma<TS>(A, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y, Lt, sa.pre_tile + pre0, sa.pre_col + pre0, npre, s_g, S,
-                                         Linv, sm + 2 * TS * LD);
-    if (!ok) { if (tid == 0) *status = k + 1; return; }
+    const int rc = potrf_sweep_mfma<TS>(A, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y, Lt, sa.pre_tile + pre0, sa.pre_col + pre0, npre, s_g, S,
+                                        Linv, sm + 2 * TS * LD, status, inl, rec.pre_tile[0], rec.pre_tile[1], rec.pre_col[0], rec.pre_col[1]);
+    if (rc == 2) return;                                  // an earlier column of this trial had failed
+    if (rc == 1) { if (tid == 0) *status = k + 1; return; } // not positive definite
     if (stop_after == 5 || (stop_after >= 6 && stop_after <= 9) || stop_after == 1) return;
     __syncthreads();
     if (stop_after == 2) return;
@@ -808,6 +828,95 @@ __global__ __launch_bounds__(kPotrfThreads) void k_back_solve(const double* __re
     }
 }
 
+// The same step with the column's lists in the KERNEL ARGUMENTS (levels of at most kInlineCols columns with at most kInlineSub
+// sub-diagonal tiles each; `si` is the FIRST parameter, so it sits at offset 0 of the kernel-argument segment and is read from
+// there with scalar loads - indexing a by-value parameter would copy it to scratch memory).  Nothing here waits for an index
+// list: the rows of L_kk^-1, the x_i segments and every L_ik row this wave will use are requested in one go at the start, one
+// memory round trip instead of three dependent ones (record -> tile list -> tiles), 5.6 -> us per level at config 4.
+template <int TS>
+__global__ __launch_bounds__(kPotrfThreads) void k_back_solve_inl(SolveInline si, const double* __restrict__ Lt, const double* __restrict__ Linv, double* x,
+                                                                  const int* status)
+{
+    static_assert(TS == 48, "written for the 48-wide tile (one column set per lane)");
+    constexpr int NW = kPotrfThreads / 64, RB = 24, NRB = TS / RB, MAXU = (kInlineSub * NRB + NW - 1) / NW;
+    __shared__ double s_part[NW][TS];
+    __shared__ double s_x[NW][RB];
+    __shared__ double s_acc[TS];
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int failed = *status;
+    typedef const SolveInline __attribute__((address_space(4))) KernargSolve;
+    KernargSolve* ksi = (KernargSolve*)__builtin_amdgcn_kernarg_segment_ptr();
+    const int k = ksi->c[blockIdx.x].k, nq = ksi->c[blockIdx.x].nq;
+    const int c0 = lane < TS ? lane : TS - 1;
+    constexpr int RW = (TS + NW - 1) / NW;
+    double xv0[RW];
+    {
+        const double* X = Linv + (size_t)k * TS * TS;
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int r = wave * RW + rr < TS ? wave * RW + rr : TS - 1;
+            xv0[rr] = X[r * TS + c0];
+        }
+    }
+    double xin[MAXU], lv[MAXU][RB];
+#pragma unroll
+    for (int s = 0; s < MAXU; ++s) {
+        const int u = wave + NW * s;
+        xin[s] = 0.0;
+#pragma unroll
+        for (int w = 0; w < RB; ++w) lv[s][w] = 0.0;
+        if (u < nq * NRB) { // uniform
+            const int q = u / NRB, rb = u % NRB;
+            const int tile = ksi->c[blockIdx.x].tile[q], row = ksi->c[blockIdx.x].row[q];
+            const double* L = Lt + (size_t)tile * TS * TS + (size_t)rb * RB * TS;
+            xin[s] = x[(size_t)row * TS + rb * RB + (lane < RB ? lane : 0)];
+#pragma unroll
+            for (int w = 0; w < RB; ++w) lv[s][w] = L[w * TS + c0];
+        }
+    }
+    const double yk = tid < TS ? x[k * TS + tid] : 0.0;
+    if (failed != 0) return;
+    double a0 = 0.0, a0b = 0.0;
+#pragma unroll
+    for (int s = 0; s < MAXU; ++s) {
+        if (wave + NW * s >= nq * NRB) break; // uniform
+        __builtin_amdgcn_wave_barrier();
+        if (lane < RB) s_x[wave][lane] = xin[s];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int w = 0; w < RB; w += 2) { // two chains per column: the FMAs are latency-bound
+            a0 = fma(lv[s][w], s_x[wave][w], a0);
+            a0b = fma(lv[s][w + 1], s_x[wave][w + 1], a0b);
+        }
+    }
+    if (lane < TS) s_part[wave][lane] = a0 + a0b;
+    __syncthreads();
+    if (tid < TS) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += s_part[w][tid];
+        s_acc[tid] = yk - sum;
+    }
+    __syncthreads();
+    double b0[2] = {0.0, 0.0};
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+        const int r = wave * RW + rr;
+        const double sr = r < TS ? s_acc[r < TS ? r : 0] : 0.0;
+        b0[rr & 1] = fma(r >= c0 ? xv0[rr] : 0.0, sr, b0[rr & 1]); // Linv is lower triangular
+    }
+    __syncthreads(); // (s_part is reused)
+    if (lane < TS) s_part[wave][lane] = b0[0] + b0[1];
+    __syncthreads();
+    if (tid < TS) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += s_part[w][tid];
+        x[k * TS + tid] = sum;
+    }
+}
+
 template <int TS>
 int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n, int* status, hipStream_t s)
 {
@@ -832,12 +941,19 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
         const int t0 = p.h_tgt_ptr[st], ntg = p.h_tgt_ptr[st + 1] - t0;
         sa.n_chain = nc; sa.last_level = st == p.n_steps - 1; sa.chain_col = p.step_col + c0; sa.chain_desc = reinterpret_cast<const int4*>(p.step_desc) + 2 * c0;
         sa.tgt_tile = p.tgt_tile + t0; sa.tgt_row = p.tgt_row + t0; sa.tgt_pair_ptr = p.tgt_pair_ptr + t0;
+        if (p.h_chain_inl) sa.inl = p.h_chain_inl[st]; else sa.inl.n = 0;
         hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(nc + ntg * Q * Q), dim3(kPotrfThreads), lds_p, s, S, Lt, Linv, g, x, n, lambda, status, 0, sa);
         const int i0 = p.h_trsm_ptr[st], ni = p.h_trsm_ptr[st + 1] - i0;
         if (ni > 0 && !Fold<TS>::on) hipLaunchKernelGGL(k_trsm<TS>, dim3(ni * QT * QT), dim3(kBlock), lds_g, s, S, Lt, Linv, p.st_tile + i0, p.st_col + i0, status);
     }
     for (int st = p.n_steps - 2; st >= 0; --st) { // (the last level solved its x inside k_potrf_inv)
         const int c0 = p.h_step_ptr[st], nc = p.h_step_ptr[st + 1] - c0;
+        if constexpr (TS == 48) {
+            if (p.h_solve_inl && p.h_solve_inl[st].n == nc) {
+                hipLaunchKernelGGL(k_back_solve_inl<TS>, dim3(nc), dim3(kPotrfThreads), 0, s, p.h_solve_inl[st], Lt, Linv, x, status);
+                continue;
+            }
+        }
         hipLaunchKernelGGL(k_back_solve<TS>, dim3(nc), dim3(kPotrfThreads), 0, s, Lt, Linv, x, p, reinterpret_cast<const int4*>(p.step_desc) + 2 * c0, status);
     }
     return 0;

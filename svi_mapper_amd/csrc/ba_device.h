@@ -137,6 +137,15 @@ struct BaDev {
 };
 
 // tile-sparse Cholesky of the reduced system (ba_chol.hip)
+// What a chain workgroup has to know about its column, handed over in the KERNEL ARGUMENTS when the level is small: every
+// index list in global memory is a dependent round trip at the start of a launch (0.6 - 0.8 us each for data that sits behind
+// the L2 of another XCD), and a level's launch is on the critical path of the factorisation.
+constexpr int kInlineCols = 8, kInlinePre = 2, kInlineSub = 12;
+struct ChainRec { int k, tile, npre, pad; int pre_tile[kInlinePre], pre_col[kInlinePre]; };
+struct ChainInline { int n; int pad[3]; ChainRec c[kInlineCols]; };                      // n = 0: read the lists instead
+struct SolveRec { int k, nq; int tile[kInlineSub], row[kInlineSub]; };
+struct SolveInline { int n; int pad[3]; SolveRec c[kInlineCols]; };
+
 struct CholPlan {
     int TS = 0, NT = 0, n_steps = 0;
     // host: ranges of one dependency level (= one launch) in the device lists
@@ -161,6 +170,9 @@ struct CholPlan {
     const int* col_ptr = nullptr;     // [NT+1] sub-diagonal tiles of every column (back substitution)
     const int* trsm_tile = nullptr;
     const int* trsm_row = nullptr;
+    // host: the same per level as kernel arguments (n = 0 where a level does not fit)
+    const ChainInline* h_chain_inl = nullptr; // [n_steps]
+    const SolveInline* h_solve_inl = nullptr; // [n_steps]
 };
 
 

@@ -86,6 +86,8 @@ struct svi_ba {
     std::vector<int> pose_order;    // slot -> index into poses
     std::vector<int> lm_order;      // global landmark slot -> index into lms
     std::vector<int> h_step_ptr, h_tgt_ptr, h_trsm_ptr;
+    std::vector<svi::ChainInline> chain_inl; // per level: the chain / back-substitution records as kernel arguments (ba_chol.hip)
+    std::vector<svi::SolveInline> solve_inl;
     std::vector<int> red_perm;      // natural reduced pose index -> elimination (reduced) index
     int L0 = 0, L1 = 0;             // this rank's landmark slots [L0, L1)
     int64_t E_total = 0;

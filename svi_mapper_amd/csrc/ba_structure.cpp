@@ -936,6 +936,34 @@ int upload(Build& b)
             r[4] = b.h_col_ptr[c]; r[5] = b.h_col_ptr[c + 1] - b.h_col_ptr[c];
         }
         SVI_TRY(up.up(step_desc, &p.step_desc));
+        // the same per level as kernel arguments, where a level is small enough (ba_chol.hip)
+        ba->chain_inl.assign((size_t)b.n_steps, ChainInline{});
+        ba->solve_inl.assign((size_t)b.n_steps, SolveInline{});
+        for (int st = 0; st < b.n_steps; ++st) {
+            const int q0 = b.h_step_ptr[st], nc = b.h_step_ptr[st + 1] - q0;
+            bool chain_ok = nc <= kInlineCols, solve_ok = nc <= kInlineCols;
+            for (int q = q0; q < q0 + nc; ++q) {
+                const int c = b.step_col[q];
+                chain_ok = chain_ok && b.pre_ptr[c + 1] - b.pre_ptr[c] <= kInlinePre;
+                solve_ok = solve_ok && b.h_col_ptr[c + 1] - b.h_col_ptr[c] <= kInlineSub;
+            }
+            for (int q = q0; q < q0 + nc; ++q) {
+                const int c = b.step_col[q], i = q - q0;
+                if (chain_ok) {
+                    ChainRec& r = ba->chain_inl[st].c[i];
+                    r.k = c; r.tile = b.diag_tile[c]; r.npre = b.pre_ptr[c + 1] - b.pre_ptr[c];
+                    for (int w = 0; w < r.npre; ++w) { r.pre_tile[w] = b.pre_tile[b.pre_ptr[c] + w]; r.pre_col[w] = b.pre_col[b.pre_ptr[c] + w]; }
+                }
+                if (solve_ok) {
+                    SolveRec& r = ba->solve_inl[st].c[i];
+                    r.k = c; r.nq = b.h_col_ptr[c + 1] - b.h_col_ptr[c];
+                    for (int w = 0; w < r.nq; ++w) { r.tile[w] = b.trsm_tile[b.h_col_ptr[c] + w]; r.row[w] = b.trsm_row[b.h_col_ptr[c] + w]; }
+                }
+            }
+            ba->chain_inl[st].n = chain_ok ? nc : 0;
+            ba->solve_inl[st].n = solve_ok ? nc : 0;
+        }
+        p.h_chain_inl = ba->chain_inl.data(); p.h_solve_inl = ba->solve_inl.data();
         SVI_TRY(up.up(b.diag_tile, &p.diag_tile));
         SVI_TRY(up.up(b.pre_ptr, &p.pre_ptr));
         SVI_TRY(up.up(b.pre_tile, &p.pre_tile));

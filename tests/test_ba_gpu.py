@@ -208,6 +208,28 @@ def _nonlinear_graph(cls, tau, rot, seed=3, n_free=6, n_lm=80):
     return ba
 
 
+def test_failed_factorisation_is_a_failed_trial(svi, oracle, small):
+    """an odometry edge with NEGATIVE information makes the reduced camera system indefinite until lambda has grown: the
+    tile Cholesky has to report the non-positive pivot (it is recognised after the sweep, from the pivots the sweep stored),
+    the trial counts as failed like g2o's CHOLMOD 'not positive definite', and the LM sequence follows the oracle"""
+    def build(cls):
+        ba, _ = _make(cls, small)
+        Z = np.concatenate([np.eye(3).ravel(), [0.0, 0.0, 0.8]])
+        info = np.zeros(21)
+        info[[0, 6, 11, 15, 18, 20]] = -3e7      # the diagonal of the upper triangle
+        ba.add_edge_se3(1000005, 1000006, Z, info, robust=False)
+        ba.initialize()
+        return ba
+    g, o = build(svi.BundleAdjuster), build(oracle.OracleBA)
+    for n in (1, 2, 3):
+        assert g.optimize(n) == o.optimize(n)
+        st = g.stats()
+        assert st.lm_trials == o.trials and st.lm_iterations == o.iterations
+        assert abs(g.lm_lambda - o.lm_lambda) <= 1e-6 * o.lm_lambda
+    assert st.chol_failures > 0, "the graph was supposed to provoke failed factorisations"
+    assert _rel(g.get_poses()[1], o.get_poses()[1]) < REL
+
+
 @pytest.mark.parametrize("rot,seed", [(0.3, 3), (0.3, 9), (0.25, 1), (0.35, 6), (0.35, 8)])
 def test_rejected_trials_follow_g2o(svi, oracle, rot, seed):
     """trials are rejected (lambda *= nu, nu *= 2, state restored) before one is accepted: the accept / reject sequence,
