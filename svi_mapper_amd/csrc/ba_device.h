@@ -93,6 +93,7 @@ struct BaDev {
     double* lin_scal; // = lin_buf + 27*Pf : [0] robust chi2, [1] plain chi2, [2..2+n_ranks) max diag of H_ll per rank
     int     lin_count;
     double* block_part; // [n_lm_blocks][4 waves][4] per-wave partial sums of the landmark-major kernels
+    double* lin_part;   // the same for the linearisation (k_linearize_lm): it outlives the trial that follows, whose sums are in block_part
 
     // reduced system
     int TS, NT;            // tile edge, tiles per side
@@ -131,6 +132,8 @@ struct BaDev {
 
     // LM scalars on the device
     double* aux_part;  // [aux_blocks][2] chi2 partials of the pose-only edges
+    double* tr_part;   // [2 * 16 + 1][4] records of the workgroups of the trial's closing reduction
+    int* tr_count;     //   their arrival counter (zero between launches)
     int*    aux_count; // arrival counter of k_aux_edges (zero between launches)
     int     aux_blocks;
     double* scal;   // [8]: 0 chi_robust(trial) 1 chi_plain(trial) 2 scale_lm 3 scale_pose 4 spare...

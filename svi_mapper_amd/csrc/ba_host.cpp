@@ -30,7 +30,7 @@ void ba_linearize_lm(const BaDev& d, int cur, void* st);
 void ba_linearize_pose(const BaDev& d, int cur, void* st);
 void ba_linearize_aux(const BaDev& d, int cur, int rank, void* st);
 void ba_chi2_aux(const BaDev& d, int which, int rank, void* st);
-void ba_pose_finalize(const BaDev& d, const int* red_slot, int rank, int n_ranks, void* st);
+void ba_pose_finalize(const BaDev& d, const int* red_slot, int rank, int n_ranks, int with_invert, double lambda, void* st);
 void ba_publish(const BaDev& d, int n, double* h_scal, int* h_status, int seq, void* st);
 void ba_lin_post(const BaDev& d, int n_ranks, void* st);
 void ba_invert_landmarks(const BaDev& d, double lambda, void* st);
@@ -39,7 +39,7 @@ void ba_assemble(const BaDev& d, void* st);
 void ba_update_poses(const BaDev& d, int cur, double lambda, int scale_mode, int rank, void* st);
 void ba_backsub_chi2(const BaDev& d, int cur, double lambda, void* st);
 void ba_chi2_only(const BaDev& d, int which, void* st);
-void ba_reduce_trial_scalars(const BaDev& d, int n_pub, double* h_scal, int* h_status, int seq, void* st);
+void ba_reduce_trial_scalars(const BaDev& d, int aux_state, int with_lin, int n_pub, double* h_scal, int* h_status, int seq, void* st);
 void ba_debug_jacobians(const BaDev& d, int cur, const int* e_orig, double* err, double* Jp, double* Jl, void* st);
 void ba_debug_aux_jacobians(const BaDev& d, int cur, double* se3_err, double* se3_Ji, double* se3_Jj, double* acc_err, double* acc_J, void* st);
 void ba_configure_kernels(int TS);
@@ -162,15 +162,21 @@ int read_scalars(svi_ba* ba, int n)
 
 // sums of the trial (chi2, step scale) and their way to the host; with one rank and no profiling the reduction
 // kernel publishes them itself
-int reduce_and_read_trial(svi_ba* ba, int n)
+// aux_state: the state whose pose-only edges the reduction evaluates itself (-1: their sums are already in scal[6..7]);
+// a linearisation whose closing sums were deferred (linearize) has them taken here as well
+int reduce_and_read_trial(svi_ba* ba, int n, int aux_state)
 {
+    const int with_lin = ba->lin_post_deferred ? 1 : 0;
+    ba->lin_post_deferred = false;
+    ba->timer.begin(SVI_PH_CHI2, ba->stream);
     if (ba->opt.n_ranks == 1 && !ba->timer.on) {
         const int seq = ++ba->pub_seq;
-        ba_reduce_trial_scalars(ba->d, n, ba->h_scal, ba->h_status, seq, ba->stream);
+        ba_reduce_trial_scalars(ba->d, aux_state, with_lin, n, ba->h_scal, ba->h_status, seq, ba->stream);
         SVI_HIP(hipGetLastError());
         return wait_published(ba, seq);
     }
-    ba_reduce_trial_scalars(ba->d, 0, nullptr, nullptr, 0, ba->stream);
+    ba_reduce_trial_scalars(ba->d, aux_state, with_lin, 0, nullptr, nullptr, 0, ba->stream);
+    ba->timer.end(ba->stream);
     SVI_HIP(hipGetLastError());
     SVI_TRY(allreduce(ba, ba->d.scal, 4)); // chi2 robust / plain, landmark and pose parts of the step scale
     return read_scalars(ba, n);
@@ -188,7 +194,11 @@ int linearize(svi_ba* ba, bool read = true)
     ba->sweep_timer.end(s);
     t.begin(SVI_PH_POSE_EDGES, s);
     ba_linearize_aux(d, ba->cur, ba->opt.rank, s);
-    ba_pose_finalize(d, ba->red_slot, ba->opt.rank, ba->opt.n_ranks, s);
+    // lambda of the trial that follows is known unless this is the first linearisation of a block (lambda_0 needs max H_jj):
+    // the landmark blocks are then inverted in the same launch
+    ba->hinv_valid = !read && d.Ll > 0;
+    ba->hinv_lambda = ba->lambda;
+    ba_pose_finalize(d, ba->red_slot, ba->opt.rank, ba->opt.n_ranks, ba->hinv_valid ? 1 : 0, ba->lambda, s);
     t.end(s);
     SVI_HIP(hipGetLastError());
     // Several ranks: the pose sums (Hpp | bp | chi2 | max diag) only have to be exchanged when the host needs
@@ -198,6 +208,9 @@ int linearize(svi_ba* ba, bool read = true)
     ba->lin_local = ba->opt.n_ranks > 1 && !read && d.n_sub > 0;
     if (ba->lin_local) return SVI_OK;
     SVI_TRY(allreduce(ba, d.lin_buf, (size_t)d.lin_count));
+    // one rank, results not needed before the trial: the closing sums (chi2 of the linearisation point, max |H_jj|) are
+    // taken by the kernel that closes the trial - only the host reads them, and it reads them there
+    if (!read && ba->opt.n_ranks == 1) { ba->lin_post_deferred = true; return SVI_OK; }
     ba_lin_post(d, ba->opt.n_ranks, s);
     SVI_HIP(hipGetLastError());
     return read ? read_scalars(ba, 8) : SVI_OK; // unread: the numbers wait in scal[8..10] for the next read
@@ -221,7 +234,8 @@ int trial(svi_ba* ba, double lambda, bool* failed)
     PhaseTimer& t = ba->timer;
     // (the status word is clean: whoever read it last cleared it)
     t.begin(SVI_PH_SCHUR, s);
-    ba_invert_landmarks(d, lambda, s);
+    if (!(ba->hinv_valid && ba->hinv_lambda == lambda)) ba_invert_landmarks(d, lambda, s);
+    ba->hinv_valid = false; // (a second trial of the iteration comes with another lambda)
     ba_schur(d, s);
     t.end(s);
     t.begin(SVI_PH_ASSEMBLE, s); assemble(ba); t.end(s);
@@ -235,10 +249,7 @@ int trial(svi_ba* ba, double lambda, bool* failed)
     ba_update_poses(d, ba->cur, lambda, ba->opt.n_ranks <= 1 ? 0 : (ba->lin_local ? 2 : 1), ba->opt.rank, s);
     ba_backsub_chi2(d, ba->cur, lambda, s);
     t.end(s);
-    t.begin(SVI_PH_CHI2, s);
-    ba_chi2_aux(d, ba->cur ^ 1, ba->opt.rank, s);
-    t.end(s);
-    SVI_TRY(reduce_and_read_trial(ba, 12));
+    SVI_TRY(reduce_and_read_trial(ba, 12, ba->cur ^ 1)); // (evaluates the pose-only edges of the trial state itself)
     // with several ranks the landmark blocks (and so the status word) are local: a failure anywhere arrives as a
     // non-finite chi2 through the all-reduce, so every rank takes the same branch of the LM rule
     *failed = ba->h_status[0] != 0 || (ba->opt.n_ranks > 1 && !std::isfinite(ba->h_scal[0]));
@@ -722,8 +733,7 @@ int svi_ba_chi2(svi_ba* ba, double* plain, double* robust)
     if (!ba->have_chi) { // nothing evaluated yet: evaluate the current estimate
         SVI_HIP(hipSetDevice(ba->opt.device));
         ba_chi2_only(ba->d, ba->cur, ba->stream);
-        ba_chi2_aux(ba->d, ba->cur, ba->opt.rank, ba->stream);
-        SVI_TRY(reduce_and_read_trial(ba, 8));
+        SVI_TRY(reduce_and_read_trial(ba, 8, ba->cur)); // (the pose-only edges are evaluated by the reduction)
         ba->last_robust = ba->h_scal[0]; ba->last_plain = ba->h_scal[1]; ba->have_chi = true;
     }
     if (plain) *plain = ba->last_plain;

@@ -85,6 +85,9 @@ struct svi_ba {
     // host mirrors of the structure
     std::vector<int> pose_order;    // slot -> index into poses
     std::vector<int> lm_order;      // global landmark slot -> index into lms
+    bool hinv_valid = false;        // the landmark blocks are already inverted for hinv_lambda (done with the pose sums)
+    double hinv_lambda = 0.0;
+    bool lin_post_deferred = false; // the closing sums of the last linearisation are taken by the trial's reduction
     std::vector<int> h_step_ptr, h_tgt_ptr, h_trsm_ptr;
     std::vector<svi::ChainInline> chain_inl; // per level: the chain / back-substitution records as kernel arguments (ba_chol.hip)
     std::vector<svi::SolveInline> solve_inl;

@@ -373,11 +373,11 @@ __global__ __launch_bounds__(kBlock) void k_linearize_lm(BaDev d, int cur)
                 mx = fmax(mx, fmax(fabs(acc[0]), fmax(fabs(acc[3]), fabs(acc[5]))));
             }
         }
-        // two sums and one max per WAVE, in registers (DPP): no barrier, no serial tail; block_part holds one entry per wave
+        // two sums and one max per WAVE, in registers (DPP): no barrier, no serial tail; lin_part holds one entry per wave
         {
             const double x0 = wave_sum(part[0]), x1 = wave_sum(part[1]), x2 = wave_max(mx);
             if ((tid & 63) == 0) {
-                double* out = d.block_part + 4 * (size_t)(4 * b + (tid >> 6));
+                double* out = d.lin_part + 4 * (size_t)(4 * b + (tid >> 6));
                 out[0] = x0; out[1] = x1; out[2] = x2;
             }
         }
@@ -616,15 +616,47 @@ __global__ __launch_bounds__(kAuxThreads) void k_aux_edges(BaDev d, int which)
             r0 += __builtin_nontemporal_load(d.aux_part + 2 * b);
             r1 += __builtin_nontemporal_load(d.aux_part + 2 * b + 1);
         }
-        d.scal[6] = r0; d.scal[7] = r1;
+        // the sums of the linearisation point have slots of their own: they are read after the trial has written 6 and 7
+        d.scal[LINEARIZE ? 12 : 6] = r0; d.scal[LINEARIZE ? 13 : 7] = r1;
         *d.aux_count = 0;
     }
 }
 
-// H_pp / b_p of every free pose = sum of its chunk partials (fixed order) + its pose-only edges.
-__global__ __launch_bounds__(kBlock) void k_pose_finalize(BaDev d, const int* __restrict__ red_slot)
+// chi2 (robust, plain) of the pose-only edges at `pose`, edges k = first, first + stride, ... (the trial's closing reduction
+// evaluates them itself: a launch of its own costs more than the thousand edges)
+__device__ __forceinline__ void aux_edges_chi2(const BaDev& d, const double* __restrict__ pose, int first, int stride, double (&part)[2])
 {
-    const int idx = blockIdx.x * kBlock + threadIdx.x;
+    for (int k = first; k < d.n_se3; k += stride) {
+        const int si = d.se3_i[k], sj = d.se3_j[k];
+        double e[6], O[36];
+        se3_edge_eval(pose + 12 * si, pose + 12 * sj, d.se3_Z + 12 * k, e, nullptr, nullptr);
+        int q = 0;
+        for (int r = 0; r < 6; ++r)
+            for (int c = r; c < 6; ++c, ++q) O[6 * r + c] = O[6 * c + r] = d.se3_info[21 * k + q];
+        double c2 = 0.0;
+        for (int r = 0; r < 6; ++r)
+            for (int c = 0; c < 6; ++c) c2 += e[r] * O[6 * r + c] * e[c];
+        double w = 1.0, r0 = c2;
+        if (d.se3_robust[k]) cauchy(d.cauchy_delta, c2, r0, w);
+        part[0] += r0; part[1] += c2;
+    }
+    for (int k = first; k < d.n_accel; k += stride) {
+        const double* R = pose + 12 * d.acc_pose[k];
+        const double v[3] = {d.acc_a[3 * k], d.acc_a[3 * k + 1], d.acc_a[3 * k + 2]};
+        double e[3];
+        accel_edge_eval(R, v, e, nullptr);
+        double O[6];
+        for (int q = 0; q < 6; ++q) O[q] = d.acc_info[6 * k + q];
+        const double c2 = e[0] * (O[0] * e[0] + 2.0 * (O[1] * e[1] + O[2] * e[2])) + e[1] * (O[3] * e[1] + 2.0 * O[4] * e[2]) +
+                          e[2] * O[5] * e[2];
+        part[0] += c2; part[1] += c2;
+    }
+}
+
+// H_pp / b_p of every free pose = sum of its chunk partials (fixed order) + its pose-only edges.
+__device__ __forceinline__ void pose_finalize_block(const BaDev& d, const int* __restrict__ red_slot, int block)
+{
+    const int idx = block * kBlock + threadIdx.x;
     if (idx >= d.Pf * 27) return;
     const int r = idx / 27, v = idx % 27;
     const int s = red_slot[r];
@@ -649,6 +681,10 @@ __global__ __launch_bounds__(kBlock) void k_pose_finalize(BaDev d, const int* __
     if (v < 21) d.Hpp[(size_t)21 * r + v] = sum;
     else d.bp[(size_t)6 * r + (v - 21)] = sum;
 }
+__global__ __launch_bounds__(kBlock) void k_pose_finalize(BaDev d, const int* __restrict__ red_slot)
+{
+    pose_finalize_block(d, red_slot, blockIdx.x);
+}
 
 // chi2 (robust, plain) of the linearisation point and this rank's max |diag H_ll|.
 __global__ __launch_bounds__(kRedThreads) void k_reduce_lin_scalars(BaDev d, int rank, int n_ranks)
@@ -657,12 +693,12 @@ __global__ __launch_bounds__(kRedThreads) void k_reduce_lin_scalars(BaDev d, int
     __shared__ double s_red[2 * NW];
     double part[2] = {0.0, 0.0};
     double mx = 0.0;
-    for_each_part(d.block_part, 4 * d.n_lm_blocks, [&](const Part4& e) { part[0] += e.v[0]; part[1] += e.v[1]; mx = fmax(mx, e.v[2]); });
+    for_each_part(d.lin_part, 4 * d.n_lm_blocks, [&](const Part4& e) { part[0] += e.v[0]; part[1] += e.v[1]; mx = fmax(mx, e.v[2]); });
     block_sum<2, NW>(part, s_red);
     mx = block_max<NW>(mx, s_red);
     if (threadIdx.x == 0) {
-        d.lin_scal[0] = part[0] + d.scal[6];
-        d.lin_scal[1] = part[1] + d.scal[7];
+        d.lin_scal[0] = part[0] + d.scal[12];
+        d.lin_scal[1] = part[1] + d.scal[13];
         for (int k = 0; k < n_ranks; ++k) d.lin_scal[2 + k] = (k == rank) ? mx : 0.0;
     }
 }
@@ -677,8 +713,8 @@ __global__ __launch_bounds__(kRedThreads) void k_lin_post(BaDev d, int n_ranks)
     double mx = 0.0;
     double part[2] = {0.0, 0.0};
     // the sums of the pose-only edges (or, with several ranks, the exchanged totals): fetched first, used last
-    const double t0 = SINGLE ? d.scal[6] : d.lin_scal[0], t1 = SINGLE ? d.scal[7] : d.lin_scal[1];
-    if (SINGLE) for_each_part(d.block_part, 4 * d.n_lm_blocks, [&](const Part4& e) { part[0] += e.v[0]; part[1] += e.v[1]; mx = fmax(mx, e.v[2]); });
+    const double t0 = SINGLE ? d.scal[12] : d.lin_scal[0], t1 = SINGLE ? d.scal[13] : d.lin_scal[1];
+    if (SINGLE) for_each_part(d.lin_part, 4 * d.n_lm_blocks, [&](const Part4& e) { part[0] += e.v[0]; part[1] += e.v[1]; mx = fmax(mx, e.v[2]); });
     for (int i = threadIdx.x; i < d.Pf * 6; i += kRedThreads) {
         const int r = i / 6, a = i % 6;
         // diagonal entry a of the upper-triangle packing: index = a*6 - a(a-1)/2
@@ -700,10 +736,9 @@ __global__ __launch_bounds__(kRedThreads) void k_lin_post(BaDev d, int n_ranks)
 // K4a: (H_ll + lambda I)^-1 per landmark (upper triangle). A non positive definite block marks the
 // trial as failed, like the factorisation of the full system would.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(kBlock) void k_invert_landmarks(BaDev d, double lambda)
+__device__ __forceinline__ void invert_landmarks_block(const BaDev& d, double lambda, int block, double (*s_rec)[9])
 {
-    __shared__ double s_rec[kBlock][9]; // odd row stride: conflict-free both ways
-    const int l0 = blockIdx.x * kBlock, tid = threadIdx.x, l = l0 + tid;
+    const int l0 = block * kBlock, tid = threadIdx.x, l = l0 + tid;
     const size_t Ll = d.Ll;
     if (l < d.Ll) {
         double inv[6] = {0, 0, 0, 0, 0, 0};
@@ -734,6 +769,20 @@ __global__ __launch_bounds__(kBlock) void k_invert_landmarks(BaDev d, double lam
         const int r = i / 12, k = i - 12 * r;
         if (k < 9) out[i] = s_rec[r][k];
     }
+}
+__global__ __launch_bounds__(kBlock) void k_invert_landmarks(BaDev d, double lambda)
+{
+    __shared__ double s_rec[kBlock][9]; // odd row stride: conflict-free both ways
+    invert_landmarks_block(d, lambda, blockIdx.x, s_rec);
+}
+// The first trial of an iteration whose lambda is already known (every iteration but the first of a block): the landmark
+// blocks are inverted by extra workgroups of the launch that sums the pose blocks - the two do not depend on each other, and a
+// launch of its own costs more than either.
+__global__ __launch_bounds__(kBlock) void k_finalize_invert(BaDev d, const int* __restrict__ red_slot, int fin_blocks, double lambda)
+{
+    __shared__ double s_rec[kBlock][9];
+    if ((int)blockIdx.x < fin_blocks) pose_finalize_block(d, red_slot, blockIdx.x);
+    else invert_landmarks_block(d, lambda, (int)blockIdx.x - fin_blocks, s_rec);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1223,35 +1272,92 @@ __device__ __forceinline__ void publish_scalars(const double* scal, int n, int* 
     __hip_atomic_store(h_status + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
-// scal[0] robust chi2, scal[1] plain chi2, scal[2] landmark part of the step scale (trial state);
-// n_pub > 0 (one rank): publishes scal[0..n_pub) to the host in the same launch
-__global__ __launch_bounds__(kRedThreads) void k_reduce_trial(BaDev d, int n_pub, double* h_scal, int* h_status, int seq)
+// scal[0] robust chi2, scal[1] plain chi2, scal[2] landmark part of the step scale (trial state `which`);
+// n_pub > 0 (one rank): publishes scal[0..n_pub) to the host in the same launch.
+// AUX: the pose-only edges of the trial state are evaluated here (no k_aux_edges<false> launch in front).
+// LIN: the sums of the LINEARISATION this trial started from (k_lin_post's work: chi2 of the linearisation point, max |H_jj|)
+//      are taken here as well - in all but the first iteration of a block only the host reads them, together with the trial.
+// Several workgroups: one CU reading the 410 KB of per-wave partials of config 4 needs 4 us for that alone, and the thousand
+// pose-only edges are a long dependent computation per lane.  Roles by workgroup: [0, G) sum a slice of the trial's partials,
+// [G, 2G) (LIN) a slice of the linearisation's (the first of them also max |diag H_pp|), the last one (AUX) evaluates the
+// pose-only edges.  Every workgroup leaves one record; the LAST to arrive adds the records in workgroup order (fixed order:
+// the result does not depend on which one that is) and publishes.
+constexpr int kRedGroups = 16;
+template <bool AUX, bool LIN>
+__global__ __launch_bounds__(kRedThreads) void k_reduce_trial(BaDev d, int which, int n_pub, double* h_scal, int* h_status, int seq)
 {
-    constexpr int NW = kRedThreads / 64;
+    constexpr int NW = kRedThreads / 64, G = kRedGroups;
     __shared__ double s_red[3 * NW];
-    double part[3] = {0.0, 0.0, 0.0};
-    // what thread 0 adds or passes on at the end (written by earlier launches): fetched before the reduction, not after
-    // it as one more dependent round trip
-    double pre[12];
-#pragma unroll
-    for (int i = 0; i < 12; ++i) pre[i] = d.scal[i];
-    const int st = *d.chol_status;
-    for_each_part(d.block_part, 4 * d.n_lm_blocks, [&](const Part4& e) { part[0] += e.v[0]; part[1] += e.v[1]; part[2] += e.v[2]; });
-    block_sum<3, NW>(part, s_red);
-    if (threadIdx.x == 0) {
-        double fresh[3] = {part[0] + pre[6], part[1] + pre[7], part[2]};
-        // several ranks: a rank whose own landmark blocks or factorisation failed must fail the trial everywhere -
-        // its chi2 goes out as +inf, which survives the sum of the all-reduce (ba_host.cpp trial())
-        if (n_pub == 0 && st != 0) fresh[0] = __builtin_inf();
-        d.scal[0] = fresh[0]; d.scal[1] = fresh[1]; d.scal[2] = fresh[2];
-        if (n_pub > 0) {
-#pragma unroll
-            for (int i = 0; i < 12; ++i)
-                if (i < n_pub) __hip_atomic_store(h_scal + i, i < 3 ? fresh[i] : pre[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            __hip_atomic_store(h_status, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            *d.chol_status = 0;
-            __hip_atomic_store(h_status + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    __shared__ int s_last;
+    const int b = blockIdx.x, n_part = 4 * d.n_lm_blocks;
+    double out[3] = {0.0, 0.0, 0.0};
+    if (b < (LIN ? 2 * G : G)) {
+        const bool lin = LIN && b >= G;
+        const int g = lin ? b - G : b;
+        const Part4* __restrict__ src = reinterpret_cast<const Part4*>(lin ? d.lin_part : d.block_part);
+        const int chunk = (n_part + G - 1) / G, i0 = g * chunk, i1 = min(n_part, i0 + chunk);
+        double mx = 0.0;
+        for (int i = i0 + (int)threadIdx.x; i < i1; i += kRedThreads) {
+            const Part4 e = src[i];
+            out[0] += e.v[0]; out[1] += e.v[1];
+            if (lin) mx = fmax(mx, e.v[2]); else out[2] += e.v[2];
         }
+        if (lin && g == 0)
+            for (int i = threadIdx.x; i < d.Pf * 6; i += kRedThreads) {
+                const int r = i / 6, a = i % 6; // diagonal entry a of the upper-triangle packing: index = a*6 - a(a-1)/2
+                mx = fmax(mx, fabs(d.Hpp[(size_t)21 * r + (a * 6 - a * (a - 1) / 2)]));
+            }
+        block_sum<3, NW>(out, s_red);
+        if (lin) out[2] = block_max<NW>(mx, s_red);
+    } else if (AUX) {
+        double ap[2] = {0.0, 0.0};
+        aux_edges_chi2(d, d.pose[which], (int)threadIdx.x, kRedThreads, ap);
+        out[0] = ap[0]; out[1] = ap[1];
+        block_sum<3, NW>(out, s_red);
+    }
+    if (threadIdx.x == 0) {
+        double* rec = d.tr_part + 4 * (size_t)b;
+        rec[0] = out[0]; rec[1] = out[1]; rec[2] = out[2];
+        __threadfence();
+        s_last = (atomicAdd(d.tr_count, 1) == (int)gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!s_last || threadIdx.x != 0) return;
+    __threadfence();
+    double pre[14];
+#pragma unroll
+    for (int i = 0; i < 14; ++i) pre[i] = __builtin_nontemporal_load(d.scal + i);
+    const int st = *d.chol_status;
+    double t[3] = {0.0, 0.0, 0.0}, l[2] = {0.0, 0.0}, mx = 0.0;
+    for (int g = 0; g < G; ++g) {
+        const double* rec = d.tr_part + 4 * (size_t)g;
+        t[0] += __builtin_nontemporal_load(rec); t[1] += __builtin_nontemporal_load(rec + 1); t[2] += __builtin_nontemporal_load(rec + 2);
+    }
+    if (LIN)
+        for (int g = G; g < 2 * G; ++g) {
+            const double* rec = d.tr_part + 4 * (size_t)g;
+            l[0] += __builtin_nontemporal_load(rec); l[1] += __builtin_nontemporal_load(rec + 1); mx = fmax(mx, __builtin_nontemporal_load(rec + 2));
+        }
+    const double* arec = d.tr_part + 4 * (size_t)(LIN ? 2 * G : G);
+    const double a0 = AUX ? __builtin_nontemporal_load(arec) : pre[6], a1 = AUX ? __builtin_nontemporal_load(arec + 1) : pre[7];
+    double fresh[3] = {t[0] + a0, t[1] + a1, t[2]};
+    // several ranks: a rank whose own landmark blocks or factorisation failed must fail the trial everywhere -
+    // its chi2 goes out as +inf, which survives the sum of the all-reduce (ba_host.cpp trial())
+    if (n_pub == 0 && st != 0) fresh[0] = __builtin_inf();
+    d.scal[0] = fresh[0]; d.scal[1] = fresh[1]; d.scal[2] = fresh[2];
+    if (AUX) { d.scal[6] = a0; d.scal[7] = a1; }
+    if (LIN) { // (slots 12, 13: the pose-only edges at the linearisation point, k_aux_edges<true>)
+        pre[8] = l[0] + pre[12]; pre[9] = l[1] + pre[13]; pre[10] = mx; pre[5] = mx;
+        d.scal[5] = mx; d.scal[8] = pre[8]; d.scal[9] = pre[9]; d.scal[10] = mx;
+    }
+    *d.tr_count = 0;
+    if (n_pub > 0) {
+#pragma unroll
+        for (int i = 0; i < 12; ++i)
+            if (i < n_pub) __hip_atomic_store(h_scal + i, i < 3 ? fresh[i] : pre[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(h_status, st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        *d.chol_status = 0;
+        __hip_atomic_store(h_status + 1, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
     }
 }
 
@@ -1336,9 +1442,12 @@ void ba_chi2_aux(const BaDev& d, int which, int, void* st)
 {
     hipLaunchKernelGGL((k_aux_edges<false>), dim3(d.aux_blocks), dim3(kAuxThreads), 0, S_(st), d, which);
 }
-void ba_pose_finalize(const BaDev& d, const int* red_slot, int rank, int n_ranks, void* st)
+// with_invert: the landmark blocks are inverted for `lambda` in the same launch (ba_invert_landmarks is then not needed)
+void ba_pose_finalize(const BaDev& d, const int* red_slot, int rank, int n_ranks, int with_invert, double lambda, void* st)
 {
-    if (d.Pf > 0) hipLaunchKernelGGL(k_pose_finalize, dim3((d.Pf * 27 + kBlock - 1) / kBlock), dim3(kBlock), 0, S_(st), d, red_slot);
+    const int fb = (d.Pf * 27 + kBlock - 1) / kBlock, ib = with_invert ? (d.Ll + kBlock - 1) / kBlock : 0;
+    if (ib > 0) hipLaunchKernelGGL(k_finalize_invert, dim3(fb + ib), dim3(kBlock), 0, S_(st), d, red_slot, fb, lambda);
+    else if (d.Pf > 0) hipLaunchKernelGGL(k_pose_finalize, dim3(fb), dim3(kBlock), 0, S_(st), d, red_slot);
     if (n_ranks > 1) hipLaunchKernelGGL(k_reduce_lin_scalars, dim3(1), dim3(kRedThreads), 0, S_(st), d, rank, n_ranks);
 }
 void ba_lin_post(const BaDev& d, int n_ranks, void* st)
@@ -1374,9 +1483,15 @@ void ba_chi2_only(const BaDev& d, int which, void* st)
     if (d.info_planes == 3) hipLaunchKernelGGL((k_backsub_chi2<false, true>), dim3(d.n_lm_blocks), dim3(kBlock), 0, S_(st), d, which, 0.0);
     else hipLaunchKernelGGL((k_backsub_chi2<false, false>), dim3(d.n_lm_blocks), dim3(kBlock), 0, S_(st), d, which, 0.0);
 }
-void ba_reduce_trial_scalars(const BaDev& d, int n_pub, double* h_scal, int* h_status, int seq, void* st)
+// aux_state >= 0: evaluate the pose-only edges of that state here; with_lin: also the sums k_lin_post would have taken
+void ba_reduce_trial_scalars(const BaDev& d, int aux_state, int with_lin, int n_pub, double* h_scal, int* h_status, int seq, void* st)
 {
-    hipLaunchKernelGGL(k_reduce_trial, dim3(1), dim3(kRedThreads), 0, S_(st), d, n_pub, h_scal, h_status, seq);
+    const int w = aux_state >= 0 ? aux_state : 0, aux = aux_state >= 0 ? 1 : 0;
+    const dim3 grid(kRedGroups * (with_lin ? 2 : 1) + aux);
+    if (aux && with_lin) hipLaunchKernelGGL((k_reduce_trial<true, true>), grid, dim3(kRedThreads), 0, S_(st), d, w, n_pub, h_scal, h_status, seq);
+    else if (aux) hipLaunchKernelGGL((k_reduce_trial<true, false>), grid, dim3(kRedThreads), 0, S_(st), d, w, n_pub, h_scal, h_status, seq);
+    else if (with_lin) hipLaunchKernelGGL((k_reduce_trial<false, true>), grid, dim3(kRedThreads), 0, S_(st), d, w, n_pub, h_scal, h_status, seq);
+    else hipLaunchKernelGGL((k_reduce_trial<false, false>), grid, dim3(kRedThreads), 0, S_(st), d, w, n_pub, h_scal, h_status, seq);
 }
 void ba_debug_jacobians(const BaDev& d, int cur, const int* e_orig, double* err, double* Jp, double* Jl, void* st)
 {

@@ -883,6 +883,7 @@ int upload(Build& b)
     SVI_TRY(up.alloc((size_t)d.lin_count, &d.lin_buf));
     d.Hpp = d.lin_buf; d.bp = d.lin_buf + (size_t)21 * Pf; d.lin_scal = d.lin_buf + (size_t)27 * Pf;
     SVI_TRY(up.alloc((size_t)16 * std::max(b.n_lm_blocks, 1), &d.block_part));
+    SVI_TRY(up.alloc((size_t)16 * std::max(b.n_lm_blocks, 1), &d.lin_part));
     d.TS = TS; d.NT = NT; d.n_tiles = n_tiles;
     SVI_TRY(up.up(b.tile_map, &d.tile_map));
     // [ g | tiles with contributions | fill-in tiles ]: the all-reduce payload is the prefix g + contributing tiles
@@ -915,6 +916,8 @@ int upload(Build& b)
     d.aux_blocks = std::max(1, (std::max(d.n_se3, d.n_accel) + 63) / 64);
     SVI_TRY(up.alloc((size_t)2 * d.aux_blocks, &d.aux_part));
     SVI_TRY(up.alloc(1, &d.aux_count));
+    SVI_TRY(up.alloc((size_t)4 * 40, &d.tr_part));
+    SVI_TRY(up.alloc(1, &d.tr_count));
     if (o.n_ranks > 1) SVI_TRY(up.alloc((size_t)3 * b.Ltot, &ba->lm_all));
 
     CholPlan& p = ba->plan;
@@ -1004,6 +1007,8 @@ int reupload_state(svi_ba* ba)
     }
     SVI_HIP(hipMemsetAsync(d.chol_status, 0, sizeof(int), ba->stream));
     SVI_HIP(hipMemsetAsync(d.aux_count, 0, sizeof(int), ba->stream));
+    SVI_HIP(hipMemsetAsync(d.tr_count, 0, sizeof(int), ba->stream));
+    ba->hinv_valid = false; ba->lin_post_deferred = false;
     ba->h_status[0] = ba->h_status[1] = 0;
     ba->pub_seq = 0;
     ba->lin_local = false;

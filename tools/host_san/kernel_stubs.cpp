@@ -7,7 +7,7 @@ void ba_linearize_lm(const BaDev&, int, void*) {}
 void ba_linearize_pose(const BaDev&, int, void*) {}
 void ba_linearize_aux(const BaDev&, int, int, void*) {}
 void ba_chi2_aux(const BaDev&, int, int, void*) {}
-void ba_pose_finalize(const BaDev&, const int*, int, int, void*) {}
+void ba_pose_finalize(const BaDev&, const int*, int, int, int, double, void*) {}
 void ba_publish(const BaDev&, int, double*, int*, int, void*) {}
 void ba_lin_post(const BaDev&, int, void*) {}
 void ba_invert_landmarks(const BaDev&, double, void*) {}
@@ -16,7 +16,7 @@ void ba_assemble(const BaDev&, void*) {}
 void ba_update_poses(const BaDev&, int, double, int, int, void*) {}
 void ba_backsub_chi2(const BaDev&, int, double, void*) {}
 void ba_chi2_only(const BaDev&, int, void*) {}
-void ba_reduce_trial_scalars(const BaDev&, int, double*, int*, int, void*) {}
+void ba_reduce_trial_scalars(const BaDev&, int, int, int, double*, int*, int, void*) {}
 void ba_debug_jacobians(const BaDev&, int, const int*, double*, double*, double*, void*) {}
 void ba_debug_aux_jacobians(const BaDev&, int, double*, double*, double*, double*, double*, void*) {}
 void ba_gather_edges(const double*, const uint8_t*, const int*, const int*, int, int, int, double*, uint8_t*, const int*, int*, void*) {}
