@@ -290,7 +290,7 @@ int download_state(svi_ba* ba)
 int ensure_host(svi_ba* ba)
 {
     if (!ba->host_stale) return SVI_OK;
-    SVI_HIP(hipSetDevice(ba->opt.device));
+    SVI_HIP(svi::enter_device(ba->opt.device));
     SVI_TRY(download_state(ba));
     ba->host_stale = false;
     return SVI_OK;
@@ -301,7 +301,7 @@ namespace {
 int optimize_block(svi_ba* ba, int iterations, int* performed)
 {
     if (!ba->initialized) return fail(SVI_ERR_STATE, "svi_ba_optimize before svi_ba_initialize");
-    SVI_HIP(hipSetDevice(ba->opt.device));
+    SVI_HIP(svi::enter_device(ba->opt.device));
     const svi_ba_options& o = ba->opt;
     int done = 0;
     for (int it = 0; it < iterations; ++it) {
@@ -384,7 +384,7 @@ int edges_push(svi_ba* ba, int type, int robust, int pose, int lm, const double*
     if (i == e.cap) { // the pinned array doubles; copies that may still read the old one are drained first
         const size_t cap = std::max<size_t>(2 * e.cap, 4096);
         double* nv = nullptr;
-        SVI_HIP(hipSetDevice(ba->opt.device));
+        SVI_HIP(svi::enter_device(ba->opt.device));
         SVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&nv), cap * 72));
         if (e.vals) {
             SVI_HIP(hipStreamSynchronize(ba->stream));
@@ -418,7 +418,7 @@ int edges_flush(svi_ba* ba)
     EdgeStore& e = ba->proj;
     const size_t E = e.size();
     if (ba->raw_uploaded >= E) return SVI_OK;
-    SVI_HIP(hipSetDevice(ba->opt.device));
+    SVI_HIP(svi::enter_device(ba->opt.device));
     if (E > ba->raw_cap) { // grow the device log: new buffers, the uploaded part moves device to device
         const size_t cap = std::max<size_t>({2 * ba->raw_cap, E, (size_t)4096});
         DevBuf nl, nf;
@@ -731,7 +731,7 @@ int svi_ba_chi2(svi_ba* ba, double* plain, double* robust)
     if (!ba) return fail(SVI_ERR_INVALID, "null handle");
     if (!ba->initialized) return fail(SVI_ERR_STATE, "svi_ba_chi2 before svi_ba_initialize");
     if (!ba->have_chi) { // nothing evaluated yet: evaluate the current estimate
-        SVI_HIP(hipSetDevice(ba->opt.device));
+        SVI_HIP(svi::enter_device(ba->opt.device));
         ba_chi2_only(ba->d, ba->cur, ba->stream);
         SVI_TRY(reduce_and_read_trial(ba, 8, ba->cur)); // (the pose-only edges are evaluated by the reduction)
         ba->last_robust = ba->h_scal[0]; ba->last_plain = ba->h_scal[1]; ba->have_chi = true;
@@ -928,7 +928,7 @@ int svi_ba_debug_edge_jacobians(svi_ba* ba, double* err, double* J_pose, double*
 {
     if (!ba || !err || !J_pose || !J_lm) return fail(SVI_ERR_INVALID, "null argument");
     if (!ba->initialized) return fail(SVI_ERR_STATE, "debug tap before svi_ba_initialize");
-    SVI_HIP(hipSetDevice(ba->opt.device));
+    SVI_HIP(svi::enter_device(ba->opt.device));
     const size_t E = ba->proj.size();
     double *de = nullptr, *dp = nullptr, *dl = nullptr;
     SVI_HIP(hipMalloc(reinterpret_cast<void**>(&de), sizeof(double) * 30 * std::max<size_t>(E, 1)));
@@ -950,7 +950,7 @@ int svi_ba_debug_aux_jacobians(svi_ba* ba, double* se3_err, double* se3_Ji, doub
     if (!ba || !se3_err || !se3_Ji || !se3_Jj || !acc_err || !acc_J) return fail(SVI_ERR_INVALID, "null argument");
     if (!ba->initialized) return fail(SVI_ERR_STATE, "debug tap before svi_ba_initialize");
     if (ba->opt.rank != 0) return fail(SVI_ERR_STATE, "pose-only edges live on rank 0");
-    SVI_HIP(hipSetDevice(ba->opt.device));
+    SVI_HIP(svi::enter_device(ba->opt.device));
     const size_t ns = ba->se3.size(), na = ba->acc.size(), total = 78 * ns + 21 * na;
     double* dev = nullptr;
     SVI_HIP(hipMalloc(reinterpret_cast<void**>(&dev), sizeof(double) * std::max<size_t>(total, 1)));
@@ -988,7 +988,7 @@ static int time_sweep_impl(svi_ba* ba, int reps, int which, double* ms_avg)
 {
     if (!ba || !ms_avg || reps < 1) return fail(SVI_ERR_INVALID, "bad argument");
     if (!ba->initialized) return fail(SVI_ERR_STATE, "debug tap before svi_ba_initialize");
-    SVI_HIP(hipSetDevice(ba->opt.device));
+    SVI_HIP(svi::enter_device(ba->opt.device));
     hipEvent_t a, b;
     SVI_HIP(hipEventCreate(&a));
     SVI_HIP(hipEventCreate(&b));
@@ -1014,7 +1014,7 @@ int svi_ba_debug_time_sweep_cold(svi_ba* ba, int reps, size_t evict_bytes, doubl
 {
     if (!ba || !ms_avg || reps < 1 || evict_bytes == 0) return fail(SVI_ERR_INVALID, "bad argument");
     if (!ba->initialized) return fail(SVI_ERR_STATE, "debug tap before svi_ba_initialize");
-    SVI_HIP(hipSetDevice(ba->opt.device));
+    SVI_HIP(svi::enter_device(ba->opt.device));
     void* scratch = nullptr;
     SVI_HIP(hipMalloc(&scratch, evict_bytes));
     std::vector<hipEvent_t> ev((size_t)2 * reps);
@@ -1046,7 +1046,7 @@ int svi_ba_debug_reduced_system(svi_ba* ba, double lambda, double* S, double* g,
 {
     if (!ba || !S || !g || !n_out) return fail(SVI_ERR_INVALID, "null argument");
     if (!ba->initialized) return fail(SVI_ERR_STATE, "debug tap before svi_ba_initialize");
-    SVI_HIP(hipSetDevice(ba->opt.device));
+    SVI_HIP(svi::enter_device(ba->opt.device));
     BaDev& d = ba->d;
     const int64_t n = 6 * (int64_t)d.Pf;
     *n_out = n;

@@ -5,6 +5,7 @@
 
 #include <cstdint>
 #include <unordered_map>
+#include <memory>
 #include <vector>
 
 #include "ba_device.h"
@@ -85,6 +86,7 @@ struct svi_ba {
     // host mirrors of the structure
     std::vector<int> pose_order;    // slot -> index into poses
     std::vector<int> lm_order;      // global landmark slot -> index into lms
+    std::shared_ptr<void> build_ctx; // ba_structure.cpp's working set, kept so that its vectors keep their memory
     bool hinv_valid = false;        // the landmark blocks are already inverted for hinv_lambda (done with the pose sums)
     double hinv_lambda = 0.0;
     bool lin_post_deferred = false; // the closing sums of the last linearisation are taken by the trial's reduction

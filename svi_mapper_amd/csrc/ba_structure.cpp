@@ -78,6 +78,7 @@ struct Build {
     std::vector<int> g_edge, g_pose, g_ptr;
     // which free poses share a landmark: lower triangle over NATURAL reduced indices (only for Pf <= 4096: 16 MB), longest track
     std::vector<uint8_t> cpl;
+    std::vector<int> cpl_lo;    // first coupled column of every row of cpl (the matrix is a band: scans start there)
     bool use_cpl = false;
     int span = 0;
     // this rank
@@ -99,6 +100,25 @@ struct Build {
     int64_t total_pairs = 0;
     std::vector<int> sub_cx, sub_cy, sub_tile, it_pack, qj_begin, qj_end, qj_diag, job_len, cell_qj_ptr, cell_qj, sub_aux_ptr, sub_aux_ref;
 
+    // the context lives in the handle: the vectors keep their memory from one svi_ba_initialize to the next (a fresh 15 MB
+    // vector costs up to 3 ms of page faults on a busy box), so every one of them is emptied here (list generated from the
+    // member declarations above)
+    void clear_all()
+    {
+        pose_slot.clear(); pose_red.clear(); red_slot.clear(); lm_slot.clear(); g_edge.clear(); g_pose.clear(); g_ptr.clear();
+        cpl.clear(); cpl_lo.clear(); loc.clear(); e_pose.clear(); e_lm.clear(); lm_ptr.clear(); lb_lm.clear(); pm.clear();
+        pm_src.clear(); chunk_pose.clear(); chunk_begin.clear(); pose_chunk_ptr.clear(); lm_fixed.clear(); se3_i.clear();
+        se3_j.clear(); acc_pose.clear(); ll_free.clear(); lm_ll_ptr.clear(); pose_aux_ptr.clear(); pose_aux_ref.clear();
+        se3_Z.clear(); se3_info.clear(); acc_a.clear(); acc_info.clear(); ll_ref.clear(); ll_z.clear(); ll_info.clear();
+        se3_robust.clear(); ll_robust.clear(); tile_map.clear(); tile_ti.clear(); tile_tj.clear(); h_col_ptr.clear();
+        trsm_tile.clear(); trsm_row.clear(); diag_tile.clear(); level.clear(); h_step_ptr.clear(); step_col.clear();
+        pre_ptr.clear(); pre_tile.clear(); pre_col.clear(); h_tgt_ptr.clear(); tgt_tile.clear(); tgt_row.clear();
+        tgt_pair_ptr.clear(); pair_a.clear(); pair_b.clear(); pair_src.clear(); h_trsm_ptr.clear(); st_tile.clear();
+        st_col.clear(); sub_cx.clear(); sub_cy.clear(); sub_tile.clear(); it_pack.clear(); qj_begin.clear(); qj_end.clear();
+        qj_diag.clear(); job_len.clear(); cell_qj_ptr.clear(); cell_qj.clear(); sub_aux_ptr.clear(); sub_aux_ref.clear();
+        Pn = Pf = Ltot = 0; Etot = 0; use_cpl = false; span = 0; L0 = Ll = E = Epm = 0; n_lm_blocks = n_chunks = 0; planes = 3;
+        TS = 96; PB = 16; n = NT = n_tiles = n_tiles_orig = n_steps = 0; chol_flops = 0.0; n_sub = n_items = n_jobs = 0; total_pairs = 0;
+    }
     void mark(int k) const
     {
         if (dbg) fprintf(stderr, "build_structure: section %d starts at %.2f ms\n", k, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
@@ -201,18 +221,31 @@ void pose_coupling(Build& b)
     b.use_cpl = Pf <= 4096; // longer sequences walk the landmarks where the matrix would be read
     b.cpl.assign(b.use_cpl ? (size_t)Pf * Pf : 0, 0);
     b.span = 0;
+    b.cpl_lo.resize(b.use_cpl ? (size_t)Pf : 0);
+    for (int r = 0; r < (int)b.cpl_lo.size(); ++r) b.cpl_lo[r] = r;
     std::vector<int> reds; // free poses of one landmark, ascending (pose slots ascend, so do natural reduced indices)
+    // A feature track is a run of consecutive key frames, and many landmarks share theirs: a run [first, last] that has been
+    // entered once is skipped (bit (last - first) of seen[first]; longer or broken runs are always entered).
+    std::vector<uint64_t> seen(b.use_cpl ? (size_t)Pf : 0, 0);
     for (int l = 0; l < b.Ltot; ++l) {
+        int k0 = b.g_ptr[l];
+        const int k1 = b.g_ptr[l + 1];
+        while (k0 < k1 && b.pose_red[b.g_pose[k0]] < 0) ++k0; // (fixed poses have the lowest slots: their edges come first)
+        if (k0 == k1) continue;
+        const int first = b.pose_red[b.g_pose[k0]], len = b.pose_red[b.g_pose[k1 - 1]] - first;
+        const bool run = len + 1 == k1 - k0 && len < 64; // as many edges as poses between the first and the last: consecutive
+        if (b.use_cpl && run && (seen[first] >> len & 1) && len <= b.span) continue; // (first and last edge only: the common case)
         if (ba->lms[ba->lm_order[l]].fixed) continue;
+        b.span = std::max(b.span, len);
+        if (!b.use_cpl) continue;
+        if (run) seen[first] |= (uint64_t)1 << len;
         reds.clear();
-        for (int k = b.g_ptr[l]; k < b.g_ptr[l + 1]; ++k) { const int r = b.pose_red[b.g_pose[k]]; if (r >= 0) reds.push_back(r); }
-        if (reds.empty()) continue;
-        b.span = std::max(b.span, reds.back() - reds.front());
-        if (b.use_cpl)
-            for (size_t x = 0; x < reds.size(); ++x) {
-                uint8_t* row = &b.cpl[(size_t)reds[x] * Pf];
-                for (size_t y = 0; y <= x; ++y) row[reds[y]] = 1;
-            }
+        for (int k = k0; k < k1; ++k) reds.push_back(b.pose_red[b.g_pose[k]]);
+        for (size_t x = 0; x < reds.size(); ++x) {
+            uint8_t* row = &b.cpl[(size_t)reds[x] * Pf];
+            for (size_t y = 0; y <= x; ++y) row[reds[y]] = 1;
+            b.cpl_lo[reds[x]] = std::min(b.cpl_lo[reds[x]], first);
+        }
     }
 }
 
@@ -270,7 +303,7 @@ void elimination_order(Build& b)
             for (int ri = 0; ri < Pf; ++ri) {
                 const int tx = perm[ri] / PBo;
                 const uint8_t* row = &cpl[(size_t)ri * Pf];
-                for (int rj = 0; rj <= ri; ++rj)
+                for (int rj = b.cpl_lo[ri]; rj <= ri; ++rj) // (nothing is coupled in front of cpl_lo: the matrix is a band)
                     if (row[rj]) { const int ty = perm[rj] / PBo; z[(size_t)std::max(tx, ty) * NTo + std::min(tx, ty)] = 1; }
             }
         } else {
@@ -497,7 +530,7 @@ int tile_structure(Build& b)
             for (int ri = 0; ri < Pf; ++ri) {
                 const int tx = ba->red_perm[ri] / PB;
                 const uint8_t* row = &b.cpl[(size_t)ri * Pf];
-                for (int rj = 0; rj <= ri; ++rj)
+                for (int rj = b.cpl_lo[ri]; rj <= ri; ++rj)
                     if (row[rj]) { const int ty = ba->red_perm[rj] / PB; nz[(size_t)std::max(tx, ty) * NT + std::min(tx, ty)] = 1; }
             }
         } else {
@@ -693,19 +726,22 @@ int schur_work_lists(Build& b)
         lrange(t, la, lz);
         Seg seg[kLmBlockEdges];
         int* h = hist[t].data();
+        int err = 0;         // (thread-local: the per-thread slots share cache lines, a million updates each would fight over them)
+        int64_t npairs = 0;
         for (int l = la; l < lz; ++l) {
             if (b.lm_fixed[l]) continue;
             const int ns = segments(l, seg);
             for (int x = 0; x < ns; ++x)
                 for (int y = 0; y <= x; ++y) {
                     const int qx = seg[x].chunk, qy = seg[y].chunk; // qx >= qy: edges of a landmark ascend in reduced index
-                    if (qy > qx) { terr[t] = 1; continue; }
+                    if (qy > qx) { err = 1; continue; }
                     const int sub = sub_map[(size_t)(qx / 2) * NSUB + qy / 2];
-                    if (sub < 0) { terr[t] = 2; continue; }
+                    if (sub < 0) { err = 2; continue; }
                     h[4 * sub + 2 * (qx % 2) + (qy % 2)]++;
-                    tpairs[t] += (x == y) ? (int64_t)seg[x].count * (seg[x].count + 1) / 2 : (int64_t)seg[x].count * seg[y].count;
+                    npairs += (x == y) ? (int64_t)seg[x].count * (seg[x].count + 1) / 2 : (int64_t)seg[x].count * seg[y].count;
                 }
         }
+        terr[t] = err; tpairs[t] = npairs;
     });
     b.mark(62);
     int64_t pairs = 0;
@@ -750,7 +786,7 @@ int schur_work_lists(Build& b)
     // workgroup), one more would wait for a whole round.  Measured at config 4 with the current kernels (quarter jobs: Schur +
     // assemble us): 4096: 207 + 22, 6144: 185 + 27, 8192: 176 + 33, 10240: 209 + 38.
     int n_cu = 256;
-    { hipDeviceProp_t prop; if (hipGetDeviceProperties(&prop, ba->opt.device) == hipSuccess && prop.multiProcessorCount > 0) n_cu = prop.multiProcessorCount; }
+    if (const int cu = device_compute_units(ba->opt.device)) n_cu = cu;
     const int64_t qj_cap = (int64_t)4 * (n_cu * 4 * 2);
     auto pieces = [&](int len) { int64_t cnt = 0; for (int c = 0; c < n_cells; ++c) cnt += (cell_ptr[c + 1] - cell_ptr[c] + len - 1) / len; return cnt; };
     int L = 16;
@@ -1018,7 +1054,9 @@ int reupload_state(svi_ba* ba)
 
 int build_structure(svi_ba* ba)
 {
-    Build b;
+    if (!ba->build_ctx) ba->build_ctx = std::shared_ptr<void>(new Build(), [](void* p) { delete static_cast<Build*>(p); });
+    Build& b = *static_cast<Build*>(ba->build_ctx.get());
+    b.clear_all();
     b.ba = ba;
     b.dbg = getenv("SVI_DEBUG_PLAN") != nullptr;
     b.t0 = std::chrono::steady_clock::now();

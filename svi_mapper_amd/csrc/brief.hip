@@ -228,7 +228,7 @@ int svi_brief_create(svi_matcher* m, const int8_t* pattern, svi_brief** out)
     if (!m || !pattern || !out) return svi::fail(SVI_ERR_INVALID, "svi_brief_create: null argument");
     for (int t = 0; t < 1024; ++t)
         if (pattern[t] < -24 || pattern[t] > 24) return svi::fail(SVI_ERR_INVALID, "svi_brief_create: test offset %d outside the 48x48 patch", (int)pattern[t]);
-    SVI_HIP(hipSetDevice(m->device));
+    SVI_HIP(svi::enter_device(m->device));
     svi_brief* b = new svi_brief();
     b->m = m;
     if (hipMalloc(reinterpret_cast<void**>(&b->pattern), 1024) != hipSuccess) { delete b; return svi::fail(SVI_ERR_HIP, "hipMalloc failed"); }
@@ -255,7 +255,7 @@ int svi_brief_set_image_dev(svi_brief* b, int side, const uint8_t* image, int wi
     if (side < 0 || side > 1 || width <= 0 || height <= 0 || stride < width || width > 16384 || height > 16384)
         return svi::fail(SVI_ERR_INVALID, "svi_brief_set_image_dev: bad side / size");
     hipStream_t st = b->m->stream;
-    SVI_HIP(hipSetDevice(b->m->device));
+    SVI_HIP(svi::enter_device(b->m->device));
     const size_t need = sizeof(int32_t) * (size_t)(width + 1) * (height + 1);
     if (b->cap[side] < need) {
         SVI_HIP(hipStreamSynchronize(st));
@@ -274,7 +274,7 @@ int svi_brief_set_image_dev(svi_brief* b, int side, const uint8_t* image, int wi
 int svi_brief_integral_dev(svi_brief* b, int side, int32_t* out)
 {
     if (!b || !out || side < 0 || side > 1 || !b->sum[side]) return svi::fail(SVI_ERR_INVALID, "svi_brief_integral_dev: no image set");
-    SVI_HIP(hipSetDevice(b->m->device));
+    SVI_HIP(svi::enter_device(b->m->device));
     SVI_HIP(hipMemcpyAsync(out, b->sum[side], sizeof(int32_t) * (size_t)(b->w[side] + 1) * (b->h[side] + 1), hipMemcpyDeviceToDevice, b->m->stream));
     return SVI_OK;
 }
@@ -289,7 +289,7 @@ int svi_brief_compute_dev(svi_brief* b, int side, const int32_t* roi, const int3
     if (total_in > 0 && (!kp_uv || !kp_out || !desc_out)) return svi::fail(SVI_ERR_INVALID, "svi_brief_compute_dev: null key point / output array");
     if (reinterpret_cast<uintptr_t>(desc_out) & 3) return svi::fail(SVI_ERR_INVALID, "svi_brief_compute_dev: desc_out must be 4-byte aligned");
     hipStream_t st = b->m->stream;
-    SVI_HIP(hipSetDevice(b->m->device));
+    SVI_HIP(svi::enter_device(b->m->device));
     if (b->owner.cap < sizeof(int32_t) * (size_t)std::max<int64_t>(total_in, 1)) SVI_HIP(hipStreamSynchronize(st));
     if (int rc = b->owner.reserve(sizeof(int32_t) * (size_t)std::max<int64_t>(total_in, 1))) return rc;
     const int w = b->w[side], h = b->h[side];

@@ -239,7 +239,7 @@ int svi_landmarks_optimize_dev(svi_matcher* m, const svi_landmark_params* prm, c
     if (n == 0) return SVI_OK;
     if (!meas_seg || !xyz_in || !xyz_out || !out_status || !out_error_average || !out_iterations)
         return svi::fail(SVI_ERR_INVALID, "svi_landmarks_optimize_dev: null array");
-    SVI_HIP(hipSetDevice(m->device));
+    SVI_HIP(svi::enter_device(m->device));
     LmArgs a{};
     a.min_measurements = prm->min_measurements; a.cap_iterations = prm->cap_iterations;
     a.conv_delta = prm->convergence_delta; a.kernel_max = prm->kernel_max_error_l2; a.min_ratio = prm->min_inlier_ratio;

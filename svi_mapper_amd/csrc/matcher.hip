@@ -322,8 +322,7 @@ int svi_matcher_create(int device, void* stream, svi_matcher** out)
         if (e != hipSuccess) { delete m; return svi::fail(SVI_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         m->own_stream = true;
     }
-    hipDeviceProp_t prop;
-    if (hipGetDeviceProperties(&prop, device) == hipSuccess) m->n_cu = prop.multiProcessorCount;
+    if (const int cu = svi::device_compute_units(device)) m->n_cu = cu;
     *out = m;
     return SVI_OK;
 }
@@ -372,7 +371,7 @@ static int launch_match(svi_matcher* m, const uint8_t* q, int nq, const uint8_t*
     if (fuse && (!gate || !out_xyz || !out_ok)) return svi::fail(SVI_ERR_INVALID, "fused triangulation needs gate coordinates and outputs");
     if ((reinterpret_cast<uintptr_t>(q) | reinterpret_cast<uintptr_t>(t)) & 15)
         return svi::fail(SVI_ERR_INVALID, "descriptor arrays must be 16-byte aligned");
-    SVI_HIP(hipSetDevice(m->device));
+    SVI_HIP(svi::enter_device(m->device));
 
     MatchArgs a{};
     a.q = reinterpret_cast<const uint4*>(q);
@@ -460,7 +459,7 @@ __global__ __launch_bounds__(256) void k_clock_probe(int iters, unsigned* sink, 
 int svi_debug_shader_clock_mhz(svi_matcher* m, double* mhz)
 {
     if (!m || !mhz) return svi::fail(SVI_ERR_INVALID, "null argument");
-    SVI_HIP(hipSetDevice(m->device));
+    SVI_HIP(svi::enter_device(m->device));
     if (int rc = m->scratch.reserve(64)) return rc;
     double* out = m->scratch.as<double>();
     unsigned* sink = reinterpret_cast<unsigned*>(out + 4);
@@ -507,7 +506,7 @@ int svi_match_hamming256(svi_matcher* m, const uint8_t* q, int nq, const uint8_t
     if (nq < 0 || nt < 0) return svi::fail(SVI_ERR_INVALID, "negative size");
     if (nq == 0) return SVI_OK;
     if (!q || !out_idx || !out_dist || (nt > 0 && !t)) return svi::fail(SVI_ERR_INVALID, "null pointer");
-    SVI_HIP(hipSetDevice(m->device));
+    SVI_HIP(svi::enter_device(m->device));
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t oq = 0, ot = oq + al(32ull * nq), oquv = ot + al(32ull * nt), otuv = oquv + al(8ull * nq),
                  omin = otuv + al(8ull * nt), omax = omin + al(4ull * nq), oidx = omax + al(4ull * nq),
@@ -543,7 +542,7 @@ int svi_hamming256_pairs_dev(svi_matcher* m, const uint8_t* a, const uint8_t* b,
     if (n < 0) return svi::fail(SVI_ERR_INVALID, "negative size");
     if (n == 0) return SVI_OK;
     if (!a || !b || !dist) return svi::fail(SVI_ERR_INVALID, "null pointer");
-    SVI_HIP(hipSetDevice(m->device));
+    SVI_HIP(svi::enter_device(m->device));
     hipLaunchKernelGGL(k_hamming256_pairs, dim3((n + 255) / 256), dim3(256), 0, m->stream,
                        reinterpret_cast<const uint4*>(a), reinterpret_cast<const uint4*>(b), n, dist);
     SVI_HIP(hipGetLastError());
@@ -556,7 +555,7 @@ int svi_hamming256_pairs(svi_matcher* m, const uint8_t* a, const uint8_t* b, int
     if (n < 0) return svi::fail(SVI_ERR_INVALID, "negative size");
     if (n == 0) return SVI_OK;
     if (!a || !b || !dist) return svi::fail(SVI_ERR_INVALID, "null pointer");
-    SVI_HIP(hipSetDevice(m->device));
+    SVI_HIP(svi::enter_device(m->device));
     const size_t nb = 32ull * n, off_b = (nb + 255) & ~size_t(255), off_d = 2 * off_b;
     if (int rc = m->scratch.reserve(off_d + 4ull * n)) return rc;
     char* d = m->scratch.as<char>();
@@ -578,7 +577,7 @@ int svi_triangulate_rectified_dev(svi_matcher* m, double f, double cx, double cy
     if (n == 0) return SVI_OK;
     if (!uvL || !uvR || !xyz || !ok) return svi::fail(SVI_ERR_INVALID, "null pointer");
     if (!(f != 0.0)) return svi::fail(SVI_ERR_INVALID, "focal length must be non-zero");
-    SVI_HIP(hipSetDevice(m->device));
+    SVI_HIP(svi::enter_device(m->device));
     hipLaunchKernelGGL(k_triangulate, dim3((n + 255) / 256), dim3(256), 0, m->stream, reinterpret_cast<const float2*>(uvL),
                        reinterpret_cast<const float2*>(uvR), n, 1.0 / f, cx, cy, duR_flipped, min_disparity, xyz, ok);
     SVI_HIP(hipGetLastError());
@@ -592,7 +591,7 @@ int svi_triangulate_rectified(svi_matcher* m, double f, double cx, double cy, do
     if (n < 0) return svi::fail(SVI_ERR_INVALID, "negative size");
     if (n == 0) return SVI_OK;
     if (!uvL || !uvR || !xyz || !ok) return svi::fail(SVI_ERR_INVALID, "null pointer");
-    SVI_HIP(hipSetDevice(m->device));
+    SVI_HIP(svi::enter_device(m->device));
     auto al = [](size_t x) { return (x + 255) & ~size_t(255); };
     const size_t oL = 0, oR = al(8ull * n), oX = oR + al(8ull * n), oK = oX + al(24ull * n), total = oK + al(n);
     if (int rc = m->scratch.reserve(total)) return rc;

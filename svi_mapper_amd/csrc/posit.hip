@@ -254,7 +254,7 @@ int svi_stereo_posit_dev(svi_matcher* m, const svi_posit_params* prm, const doub
         return svi::fail(SVI_ERR_INVALID, "svi_stereo_posit_dev: null handle / parameter / pose / result");
     if (n < 0 || prm->max_iterations < 1) return svi::fail(SVI_ERR_INVALID, "svi_stereo_posit_dev: bad n / max_iterations");
     if (n > 0 && (!xyz_world || !uv_left || !uv_right)) return svi::fail(SVI_ERR_INVALID, "svi_stereo_posit_dev: null measurement array");
-    SVI_HIP(hipSetDevice(m->device));
+    SVI_HIP(svi::enter_device(m->device));
     if (m->track.cap < sizeof(svi_posit_result)) SVI_HIP(hipStreamSynchronize(m->stream));
     if (int rc = m->track.reserve(sizeof(svi_posit_result) + 64)) return rc;
     PositArgs a{};

@@ -630,7 +630,7 @@ int svi_tracker_plan(svi_tracker* t, const double* T_world_to_left, const double
     t->planned = false;
     svi_track_record* rec = nullptr;
     int32_t* seg = nullptr;
-    SVI_HIP(hipSetDevice(t->m->device));
+    SVI_HIP(svi::enter_device(t->m->device));
     SVI_TRY(t->take(svi_tracker::kRecords, (size_t)lm->n, &rec));
     SVI_TRY(t->take(svi_tracker::kS3Seg, (size_t)lm->n + 1, &seg));
     SVI_TRY(svi_track_plan_dev(t->m, &t->cam, T_world_to_left, dp_T_left_to_world, n_dp, motion_scaling, lm->xyz_world, lm->kp_size, lm->last_disparity,
@@ -673,7 +673,7 @@ int svi_track_stage1(svi_tracker* t, const uint8_t* active, const svi_track_resu
 {
     SVI_TRY(check_frame(t, false));
     SVI_TRY(check_result(out));
-    SVI_HIP(hipSetDevice(t->m->device));
+    SVI_HIP(svi::enter_device(t->m->device));
     init_result(t, out, t->lm.n);
     uint8_t* run = nullptr;
     SVI_TRY(make_mask(t, active, kMaskFovBoth, svi_tracker::kMaskC, &run));   // :389
@@ -684,7 +684,7 @@ int svi_track_stage2(svi_tracker* t, const uint8_t* active, const svi_track_resu
 {
     SVI_TRY(check_frame(t, false));
     SVI_TRY(check_result(out));
-    SVI_HIP(hipSetDevice(t->m->device));
+    SVI_HIP(svi::enter_device(t->m->device));
     init_result(t, out, t->lm.n);
     uint8_t* run = nullptr;
     SVI_TRY(make_mask(t, active, kMaskFovBoth, svi_tracker::kMaskC, &run));
@@ -695,7 +695,7 @@ int svi_track_epipolar(svi_tracker* t, const uint8_t* active, const svi_track_re
 {
     SVI_TRY(check_frame(t, true));
     SVI_TRY(check_result(out));
-    SVI_HIP(hipSetDevice(t->m->device));
+    SVI_HIP(svi::enter_device(t->m->device));
     init_result(t, out, t->lm.n);
     uint8_t* run = nullptr;
     SVI_TRY(make_mask(t, active, kMaskEpiOk, svi_tracker::kMaskC, &run));
@@ -712,7 +712,7 @@ int svi_track_manual(svi_tracker* t, const uint8_t* active, const svi_track_resu
 {
     SVI_TRY(check_frame(t, true));
     SVI_TRY(check_result(out));
-    SVI_HIP(hipSetDevice(t->m->device));
+    SVI_HIP(svi::enter_device(t->m->device));
     const int n = t->lm.n;
     init_result(t, out, n);
     uint8_t *run = nullptr, *lost = nullptr, *run3 = nullptr;
@@ -731,7 +731,7 @@ int svi_track_pose_stereo_posit(svi_tracker* t, const uint8_t* active, const svi
     SVI_TRY(check_frame(t, false));
     SVI_TRY(check_result(out));
     if (!prm || !pose) return svi::fail(SVI_ERR_INVALID, "svi_track_pose_stereo_posit: null parameters / result");
-    SVI_HIP(hipSetDevice(t->m->device));
+    SVI_HIP(svi::enter_device(t->m->device));
     const int n = t->lm.n;
     init_result(t, out, n);
     uint8_t *run = nullptr, *lost = nullptr;
@@ -756,7 +756,7 @@ int svi_track_add_new_landmarks(svi_tracker* t, const float* uv_left, const floa
     if (!uv_left || !kp_size || !desc_left) return svi::fail(SVI_ERR_INVALID, "svi_track_add_new_landmarks: null array");
     if (reinterpret_cast<uintptr_t>(desc_left) & 15) return svi::fail(SVI_ERR_INVALID, "svi_track_add_new_landmarks: desc_left must be 16-byte aligned");
     svi_matcher* m = t->m;
-    SVI_HIP(hipSetDevice(m->device));
+    SVI_HIP(svi::enter_device(m->device));
     svi_track_result o = *out;
     o.stage = nullptr;
     hipLaunchKernelGGL(k_init_result, grid_for(n), dim3(kB), 0, m->stream, o, n);

@@ -510,7 +510,7 @@ int svi_track_plan_dev(svi_matcher* m, const svi_track_camera* cam, const double
     if (n > 0 && (!xyz_world || !kp_size || !last_disparity || !uv_reference || !dp_index || !records))
         return svi::fail(SVI_ERR_INVALID, "svi_track_plan_dev: null array");
     if (total_samples && !s3_seg) return svi::fail(SVI_ERR_INVALID, "svi_track_plan_dev: total_samples needs s3_seg");
-    SVI_HIP(hipSetDevice(m->device));
+    SVI_HIP(svi::enter_device(m->device));
     // device staging: [T (12)] [dp_T (12 n_dp)] [F (10 n_dp)]
     const size_t nd = 12 + 12 * (size_t)n_dp + 10 * (size_t)n_dp;
     // the previous call's kernels may still read the buffer: drain before it can be re-allocated
@@ -542,7 +542,7 @@ int svi_track_epipolar_samples_dev(svi_matcher* m, const svi_track_camera* cam, 
     if (n_sel < 0 || depth < 0 || depth > 127) return svi::fail(SVI_ERR_INVALID, "svi_track_epipolar_samples_dev: bad n_sel / depth");
     if (n_sel == 0) return SVI_OK;
     if (!records || !kp_size || !seg || !sample_uv || !roi) return svi::fail(SVI_ERR_INVALID, "svi_track_epipolar_samples_dev: null array");
-    SVI_HIP(hipSetDevice(m->device));
+    SVI_HIP(svi::enter_device(m->device));
     hipLaunchKernelGGL(k_track_samples, dim3((n_sel + 3) / 4), dim3(256), 0, m->stream, static_cast<float>(cam->width),
                        static_cast<float>(cam->height), records, kp_size, sel, n_sel, seg, depth, sample_uv, roi);
     SVI_HIP(hipGetLastError());
@@ -559,7 +559,7 @@ int svi_track_handover_dev(svi_matcher* m, int mode, const svi_track_record* rec
     if (!records || !kp_size || !uv_ref || !topleft || !ok) return svi::fail(SVI_ERR_INVALID, "svi_track_handover_dev: null array");
     if (mode >= 2 && (!seg || !pool_uv || !idx)) return svi::fail(SVI_ERR_INVALID, "svi_track_handover_dev: mode %d needs seg / pool_uv / idx", mode);
     if (mode == 4 && !roi) return svi::fail(SVI_ERR_INVALID, "svi_track_handover_dev: mode 4 needs roi");
-    SVI_HIP(hipSetDevice(m->device));
+    SVI_HIP(svi::enter_device(m->device));
     hipLaunchKernelGGL(k_track_handover, dim3((n_sel + 255) / 256), dim3(256), 0, m->stream, mode, records, kp_size, sel, n_sel, seg,
                        reinterpret_cast<const float2*>(pool_uv), idx, roi, reinterpret_cast<float2*>(uv_ref), reinterpret_cast<float2*>(topleft), ok);
     SVI_HIP(hipGetLastError());
@@ -574,7 +574,7 @@ int svi_track_stereo_range_dev(svi_matcher* m, double width, int search_in_left,
     if (n < 0 || !seg) return svi::fail(SVI_ERR_INVALID, "svi_track_stereo_range_dev: bad n / seg");
     if (n > 0 && (!uv_ref || !topleft || !kp_size || !out_status || (search_in_left && !search_range)))
         return svi::fail(SVI_ERR_INVALID, "svi_track_stereo_range_dev: null array");
-    SVI_HIP(hipSetDevice(m->device));
+    SVI_HIP(svi::enter_device(m->device));
     if (n > 0)
         hipLaunchKernelGGL(k_stereo_range, dim3((n + 255) / 256), dim3(256), 0, m->stream, static_cast<float>(width), search_in_left,
                            reinterpret_cast<const float2*>(uv_ref), reinterpret_cast<const float2*>(topleft), kp_size, search_range, active, n,
@@ -590,7 +590,7 @@ int svi_track_stereo_candidates_dev(svi_matcher* m, int search_in_left, const fl
     if (n < 0) return svi::fail(SVI_ERR_INVALID, "svi_track_stereo_candidates_dev: n < 0");
     if (n == 0) return SVI_OK;
     if (!kp_size || !seg || !pool_uv) return svi::fail(SVI_ERR_INVALID, "svi_track_stereo_candidates_dev: null array");
-    SVI_HIP(hipSetDevice(m->device));
+    SVI_HIP(svi::enter_device(m->device));
     hipLaunchKernelGGL(k_stereo_candidates, dim3((n + 3) / 4), dim3(256), 0, m->stream, search_in_left, kp_size, n, seg,
                        reinterpret_cast<float2*>(pool_uv));
     SVI_HIP(hipGetLastError());
@@ -606,7 +606,7 @@ int svi_match_ragged_dev(svi_matcher* m, const uint8_t* q, const uint8_t* origin
     if (nq == 0) return SVI_OK;
     if (!q || !seg || !out_idx || !out_dist || !out_status) return svi::fail(SVI_ERR_INVALID, "svi_match_ragged_dev: null array");
     if (cutoff_relative < 0 || cutoff_original < 0) return svi::fail(SVI_ERR_INVALID, "svi_match_ragged_dev: negative cut-off");
-    SVI_HIP(hipSetDevice(m->device));
+    SVI_HIP(svi::enter_device(m->device));
     VerifyArgs va{};
     hipLaunchKernelGGL(k_match_ragged<false>, dim3((nq + 3) / 4), dim3(256), 0, m->stream, reinterpret_cast<const uint4*>(q),
                        reinterpret_cast<const uint4*>(original), active, nq, seg, reinterpret_cast<const uint4*>(pool), cutoff_relative,
@@ -627,7 +627,7 @@ int svi_track_stereo_verify_dev(svi_matcher* m, const svi_track_stereo_params* p
         return svi::fail(SVI_ERR_INVALID, "svi_track_stereo_verify_dev: null array");
     if (prm->cutoff_other >= 0 && !last_other) return svi::fail(SVI_ERR_INVALID, "svi_track_stereo_verify_dev: cutoff_other needs last_other");
     if (prm->cutoff_match < 0 || !(prm->f > 0.0)) return svi::fail(SVI_ERR_INVALID, "svi_track_stereo_verify_dev: bad parameters");
-    SVI_HIP(hipSetDevice(m->device));
+    SVI_HIP(svi::enter_device(m->device));
     VerifyArgs va{};
     va.finv = 1.0 / prm->f; va.cx = prm->cx; va.cy = prm->cy; va.dur = prm->duR_flipped; va.min_disp = prm->min_disparity;
     va.depth_min = prm->depth_min; va.depth_max = prm->depth_max;

@@ -45,7 +45,8 @@ def make_allreduce_hook(group=None):
         key = (ptr, count)
         t = cache.get(key)
         if t is None:
-            t = torch.as_tensor(_DevPtr(ptr, count), device=torch.device("cuda", torch.cuda.current_device()))
+            from . import _dlpack
+            t = _dlpack.alias(ptr, (count,), torch.float64, torch.device("cuda", torch.cuda.current_device()))
             cache[key] = t
         ext = streams.get(stream)
         if ext is None:

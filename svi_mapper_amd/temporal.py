@@ -27,7 +27,7 @@ import ctypes as C
 import numpy as np
 import torch
 
-from . import _capi
+from . import _capi, _dlpack
 from ._capi import LandmarkParams, PositParams, PositResult
 from ._capi import (MATCH_OK, MATCH_SKIPPED, TRACK_RECORD_FIELDS, TRACK_RECORD_SIZE, TrackCamera, TrackLandmarks, TrackResult,
                     TrackStereoParams, check)
@@ -40,24 +40,9 @@ def _p(t):
     return None if t is None else t.data_ptr()
 
 
-class _Alias:
-    """__cuda_array_interface__ carrier: lets torch alias library-owned device memory without a copy"""
-
-    def __init__(self, ptr, shape, typestr):
-        self.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": typestr, "data": (int(ptr), False), "version": 2,
-                                         "strides": None}
-
-
-_TYPESTR = {torch.float32: "<f4", torch.int32: "<i4", torch.uint8: "|u1", torch.float64: "<f8"}
-
-
 def _alias(ptr, shape, dtype, device):
-    n = 1
-    for x in shape:
-        n *= int(x)
-    if n == 0 or not ptr:
-        return torch.empty(tuple(shape), dtype=dtype, device=device)
-    return torch.as_tensor(_Alias(ptr, shape, _TYPESTR[dtype]), device=device)
+    """torch view of library-owned device memory, no copy (a DLPack capsule that states the device: _dlpack.py)"""
+    return _dlpack.alias(ptr, shape, dtype, device)
 
 
 class StereoCamera:

@@ -108,3 +108,21 @@ def test_devptr_array_interface():
     d = sdist._DevPtr(0x1000, 17)
     ai = d.__cuda_array_interface__
     assert ai["shape"] == (17,) and ai["typestr"] == "<f8" and ai["data"] == (0x1000, False)
+
+
+def test_dlpack_alias_states_its_device():
+    """the capsule the hooks hand to torch aliases the caller's memory (no copy), keeps its bookkeeping until torch lets go,
+    and never asks the runtime whose pointer it is (host memory here: the device case runs in the -m gpu tests)"""
+    import gc
+    import numpy as np
+    import torch
+    from svi_mapper_amd import _dlpack
+    a = np.arange(12, dtype=np.float64)
+    t = _dlpack.alias(a.ctypes.data, (3, 4), torch.float64, "cpu")
+    assert t.shape == (3, 4) and t.dtype == torch.float64 and len(_dlpack._live) == 1
+    t[1, 1] = -5.0
+    assert a[5] == -5.0
+    del t
+    gc.collect()
+    assert len(_dlpack._live) == 0
+    assert _dlpack.alias(0, (0, 2), torch.float32, "cpu").shape == (0, 2)

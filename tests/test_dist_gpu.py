@@ -22,9 +22,9 @@ def _run_sharded(svi, prob, n_ranks, iters, extra=None, make=None):
 
     def hook_for(rank):
         def hook(ptr, count, stream):
-            from svi_mapper_amd.dist import _DevPtr
+            from svi_mapper_amd import _dlpack
             ext = torch.cuda.ExternalStream(stream)
-            t = torch.as_tensor(_DevPtr(ptr, count), device="cuda:0")
+            t = _dlpack.alias(ptr, (count,), torch.float64, "cuda:0")
             ext.synchronize()
             slots[rank] = t
             barrier.wait()
