@@ -882,7 +882,7 @@ __global__ __launch_bounds__(kPotrfThreads) void k_back_solve_inl(SolveInline si
         if (wave + NW * s >= nq * NRB) break; // uniform
         __builtin_amdgcn_wave_barrier();
         if (lane < RB) s_x[wave][lane] = xin[s];
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        asm volatile("" ::: "memory"); // (ordering for the compiler only: LDS is in order inside a wave, and a release fence would wait for every L row still on its way)
         __builtin_amdgcn_wave_barrier();
 #pragma unroll
         for (int w = 0; w < RB; w += 2) { // two chains per column: the FMAs are latency-bound
