@@ -270,3 +270,18 @@ def test_shard_driven_through_rccl(svi):
     assert len(big) == st.lm_trials + len(blocks), (len(big), st.lm_trials)
     # the reduced system carries two more doubles when the pose sums ride along
     assert len(set(big)) == 3 and max(big) - sorted(set(big))[-2] == 2, sorted(set(big))
+
+
+def test_dlpack_alias_on_device(svi):
+    """the hooks and the extractor callbacks hand library-owned HBM to torch through a DLPack capsule that states the device
+    (svi_mapper_amd/_dlpack.py): the tensor aliases the memory, on the device it was told, for every dtype the library uses"""
+    import torch
+    from svi_mapper_amd import _dlpack
+    for dtype in (torch.float64, torch.float32, torch.int32, torch.uint8):
+        src = (torch.arange(24, device="cuda:0") % 7).to(dtype).reshape(4, 6).contiguous()
+        t = _dlpack.alias(src.data_ptr(), (4, 6), dtype, torch.device("cuda", 0))
+        assert t.device == src.device and t.dtype == dtype and t.data_ptr() == src.data_ptr()
+        assert torch.equal(t, src)
+        t[2, 3] = 5
+        assert src[2, 3].item() == 5
+    assert _dlpack.alias(0, (0, 4), torch.float32, torch.device("cuda", 0)).shape == (0, 4)
