@@ -76,6 +76,7 @@ struct Build {
     std::vector<int> pose_slot, pose_red, red_slot, lm_slot;
     // all projection edges sorted by (landmark slot, pose slot, insertion): insertion index and pose slot, CSR per landmark slot
     std::vector<int> g_edge, g_pose, g_ptr;
+    std::vector<int> tmp_ls, tmp_ps, tmp_cur; // sort_edges' scratch (members: they keep their memory between calls)
     // which free poses share a landmark: lower triangle over NATURAL reduced indices (only for Pf <= 4096: 16 MB), longest track
     std::vector<uint8_t> cpl;
     std::vector<int> cpl_lo;    // first coupled column of every row of cpl (the matrix is a band: scans start there)
@@ -106,16 +107,17 @@ struct Build {
     void clear_all()
     {
         pose_slot.clear(); pose_red.clear(); red_slot.clear(); lm_slot.clear(); g_edge.clear(); g_pose.clear(); g_ptr.clear();
-        cpl.clear(); cpl_lo.clear(); loc.clear(); e_pose.clear(); e_lm.clear(); lm_ptr.clear(); lb_lm.clear(); pm.clear();
-        pm_src.clear(); chunk_pose.clear(); chunk_begin.clear(); pose_chunk_ptr.clear(); lm_fixed.clear(); se3_i.clear();
-        se3_j.clear(); acc_pose.clear(); ll_free.clear(); lm_ll_ptr.clear(); pose_aux_ptr.clear(); pose_aux_ref.clear();
-        se3_Z.clear(); se3_info.clear(); acc_a.clear(); acc_info.clear(); ll_ref.clear(); ll_z.clear(); ll_info.clear();
-        se3_robust.clear(); ll_robust.clear(); tile_map.clear(); tile_ti.clear(); tile_tj.clear(); h_col_ptr.clear();
-        trsm_tile.clear(); trsm_row.clear(); diag_tile.clear(); level.clear(); h_step_ptr.clear(); step_col.clear();
-        pre_ptr.clear(); pre_tile.clear(); pre_col.clear(); h_tgt_ptr.clear(); tgt_tile.clear(); tgt_row.clear();
-        tgt_pair_ptr.clear(); pair_a.clear(); pair_b.clear(); pair_src.clear(); h_trsm_ptr.clear(); st_tile.clear();
-        st_col.clear(); sub_cx.clear(); sub_cy.clear(); sub_tile.clear(); it_pack.clear(); qj_begin.clear(); qj_end.clear();
-        qj_diag.clear(); job_len.clear(); cell_qj_ptr.clear(); cell_qj.clear(); sub_aux_ptr.clear(); sub_aux_ref.clear();
+        tmp_ls.clear(); tmp_ps.clear(); tmp_cur.clear(); cpl.clear(); cpl_lo.clear(); loc.clear(); e_pose.clear();
+        e_lm.clear(); lm_ptr.clear(); lb_lm.clear(); pm.clear(); pm_src.clear(); chunk_pose.clear(); chunk_begin.clear();
+        pose_chunk_ptr.clear(); lm_fixed.clear(); se3_i.clear(); se3_j.clear(); acc_pose.clear(); ll_free.clear();
+        lm_ll_ptr.clear(); pose_aux_ptr.clear(); pose_aux_ref.clear(); se3_Z.clear(); se3_info.clear(); acc_a.clear();
+        acc_info.clear(); ll_ref.clear(); ll_z.clear(); ll_info.clear(); se3_robust.clear(); ll_robust.clear();
+        tile_map.clear(); tile_ti.clear(); tile_tj.clear(); h_col_ptr.clear(); trsm_tile.clear(); trsm_row.clear();
+        diag_tile.clear(); level.clear(); h_step_ptr.clear(); step_col.clear(); pre_ptr.clear(); pre_tile.clear();
+        pre_col.clear(); h_tgt_ptr.clear(); tgt_tile.clear(); tgt_row.clear(); tgt_pair_ptr.clear(); pair_a.clear();
+        pair_b.clear(); pair_src.clear(); h_trsm_ptr.clear(); st_tile.clear(); st_col.clear(); sub_cx.clear(); sub_cy.clear();
+        sub_tile.clear(); it_pack.clear(); qj_begin.clear(); qj_end.clear(); qj_diag.clear(); job_len.clear();
+        cell_qj_ptr.clear(); cell_qj.clear(); sub_aux_ptr.clear(); sub_aux_ref.clear();
         Pn = Pf = Ltot = 0; Etot = 0; use_cpl = false; span = 0; L0 = Ll = E = Epm = 0; n_lm_blocks = n_chunks = 0; planes = 3;
         TS = 96; PB = 16; n = NT = n_tiles = n_tiles_orig = n_steps = 0; chol_flops = 0.0; n_sub = n_items = n_jobs = 0; total_pairs = 0;
     }
@@ -187,7 +189,8 @@ void sort_edges(Build& b)
     svi_ba* ba = b.ba;
     const size_t E = ba->proj.size();
     b.Etot = (int64_t)E;
-    std::vector<int> ls(E), ps(E);
+    std::vector<int>&ls = b.tmp_ls, &ps = b.tmp_ps;
+    ls.resize(E); ps.resize(E);
     parallel_chunks(E, 1 << 16, [&](size_t a, size_t z) {
         for (size_t i = a; i < z; ++i) { ls[i] = b.lm_slot[ba->proj.lm[i]]; ps[i] = b.pose_slot[ba->proj.pose[i]]; }
     });
@@ -198,7 +201,8 @@ void sort_edges(Build& b)
     b.g_edge.resize(E);
     b.g_pose.resize(E);
     {
-        std::vector<int> cur(b.g_ptr.begin(), b.g_ptr.end() - 1);
+        std::vector<int>& cur = b.tmp_cur;
+        cur.assign(b.g_ptr.begin(), b.g_ptr.end() - 1);
         for (size_t i = 0; i < E; ++i) { const int k = cur[ls[i]]++; b.g_edge[k] = (int)i; b.g_pose[k] = ps[i]; }
     }
     // inside a landmark: by pose slot, ties in insertion order (the segments are short and nearly always sorted already)
@@ -1070,6 +1074,7 @@ int build_structure(svi_ba* ba)
     sort_edges(b);
     b.mark(2);
     pose_coupling(b);
+    b.mark(21);
     elimination_order(b);
     b.mark(3);
     SVI_TRY(local_edges(b));
