@@ -158,3 +158,100 @@ def test_golden_ba_vectors(oracle):
     _, pl = ba.get_landmarks()
     np.testing.assert_allclose(T, g["poses"], rtol=1e-8, atol=1e-9)
     np.testing.assert_allclose(pl, g["landmarks"], rtol=1e-8, atol=1e-8)
+
+
+def test_converged_minimum_matches_scipy(oracle):
+    """An independent restatement of the cost: the residuals of the three projection edge types (g2o
+    types_slam3d), of an EdgeSE3 and of a gravity edge written in plain numpy, minimised by scipy.optimize.least_squares from
+    the same start.  The oracle's LM (run to convergence, no robust kernel so that the two costs are the same function) must
+    arrive at the same minimum: same plain chi2, same poses and landmarks.  Nothing of oracle/*.c is used on the scipy side."""
+    from scipy.optimize import least_squares
+    cam = synth.kitti_camera()
+    fx, fy, cx, cy = cam["fx"], cam["fy"], cam["cx"], cam["cy"]
+    r = np.random.default_rng(11)
+    n_free, n_lm = 4, 40
+
+    def expm(w):
+        th = np.linalg.norm(w)
+        if th < 1e-12:
+            return np.eye(3)
+        k = w / th
+        K = np.array([[0, -k[2], k[1]], [k[2], 0, -k[0]], [-k[1], k[0], 0]])
+        return np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * K @ K
+
+    R_true = [np.eye(3)] + [expm(r.normal(0, 0.05, 3)) for _ in range(n_free)]
+    t_true = [np.zeros(3)] + [np.array([0.1 * (k + 1), 0.02 * k, 0.9 * (k + 1)]) for k in range(n_free)]
+    R0 = [R_true[0]] + [R_true[k] @ expm(r.normal(0, 0.03, 3)) for k in range(1, n_free + 1)]
+    t0 = [t_true[0]] + [t_true[k] + r.normal(0, 0.15, 3) for k in range(1, n_free + 1)]
+    pts = np.stack([r.uniform(-4, 4, n_lm), r.uniform(-1.5, 1.5, n_lm), 0.9 * n_free + r.uniform(4, 20, n_lm)], 1)
+    p0 = pts + r.normal(0, 0.3, pts.shape)
+    o = oracle.OracleBA(fx, fy, cx, cy, cam["baseline_m"])
+    for k in range(n_free + 1):
+        o.add_pose(1000000 + k, synth.pose12(R0[k], t0[k]), k == 0)
+    edges = []   # (type, pose, landmark, z, sqrt information diag)
+    for l in range(n_lm):
+        o.add_landmark(l, p0[l])
+        for k in range(n_free + 1):
+            if r.uniform() < 0.25:
+                continue
+            pc = R_true[k].T @ (pts[l] - t_true[k])
+            ty = int(r.integers(0, 3))
+            uv = np.array([fx * pc[0] / pc[2] + cx, fy * pc[1] / pc[2] + cy]) + r.normal(0, 0.3, 2)
+            z = pc + r.normal(0, 0.02, 3) if ty == 0 else np.array([uv[0], uv[1], pc[2] + r.normal(0, 0.05)]) if ty == 1 else \
+                np.array([uv[0], uv[1], 1.0 / pc[2] + r.normal(0, 1e-3)])
+            info = np.array([50.0, 50.0, 80.0]) if ty == 0 else np.array([1.0, 1.0, 10.0]) if ty == 1 else np.array([1.0, 1.0, 1000.0])
+            o.add_edges_bulk([ty], [1000000 + k], [l], z[None], np.array([[info[0], 0, 0, info[1], 0, info[2]]]), [0])
+            edges.append((ty, k, l, z, np.sqrt(info)))
+    # one odometry edge (poses 2 -> 3) and one gravity edge (pose 4), both with diagonal information
+    Zr, Zt = R_true[2].T @ R_true[3] @ expm(r.normal(0, 0.01, 3)), R_true[2].T @ (t_true[3] - t_true[2]) + r.normal(0, 0.02, 3)
+    se3_info = np.zeros(21)
+    se3_info[[0, 6, 11, 15, 18, 20]] = [40.0, 40.0, 40.0, 900.0, 900.0, 900.0]
+    o.add_edge_se3(1000002, 1000003, synth.pose12(Zr, Zt), se3_info, robust=False)
+    a_meas = R_true[4].T @ np.array([0.0, 0.0, -1.0]) + r.normal(0, 0.01, 3)
+    a_meas /= np.linalg.norm(a_meas)
+    o.add_edge_accel(1000004, a_meas, None, (25.0, 0, 0, 25.0, 0, 25.0))
+    o.initialize()
+
+    def unpack(x):
+        Rs, ts = [R0[0]], [t0[0]]
+        for k in range(n_free):
+            Rs.append(R0[k + 1] @ expm(x[6 * k + 3:6 * k + 6]))
+            ts.append(t0[k + 1] + x[6 * k:6 * k + 3])
+        return Rs, ts, p0 + x[6 * n_free:].reshape(n_lm, 3)
+
+    def quat_vec(Rm):   # vector part of the unit quaternion with w >= 0
+        w = 0.5 * np.sqrt(max(1.0 + np.trace(Rm), 1e-300))
+        return np.array([Rm[2, 1] - Rm[1, 2], Rm[0, 2] - Rm[2, 0], Rm[1, 0] - Rm[0, 1]]) / (4.0 * w)
+
+    def residuals(x):
+        Rs, ts, P = unpack(x)
+        out = []
+        for ty, k, l, z, sq in edges:
+            pc = Rs[k].T @ (P[l] - ts[k])
+            if ty == 0:
+                e = pc - z
+            else:
+                e = np.array([fx * pc[0] / pc[2] + cx - z[0], fy * pc[1] / pc[2] + cy - z[1], (pc[2] if ty == 1 else 1.0 / pc[2]) - z[2]])
+            out.append(sq * e)
+        Re = Zr.T @ Rs[2].T @ Rs[3]                                   # Z^-1 Xi^-1 Xj
+        te = Zr.T @ (Rs[2].T @ (ts[3] - ts[2]) - Zt)
+        out.append(np.sqrt(se3_info[[0, 6, 11]]) * te)
+        out.append(np.sqrt(se3_info[[15, 18, 20]]) * quat_vec(Re))
+        out.append(5.0 * (Rs[4] @ a_meas + np.array([0.0, 0.0, 1.0])))  # e = R a - (0, 0, -1)
+        return np.concatenate(out)
+
+    x0 = np.zeros(6 * n_free + 3 * n_lm)
+    chi_start = float(np.sum(residuals(x0) ** 2))
+    assert abs(o.chi2()[1] - chi_start) <= 1e-9 * chi_start          # the two cost functions agree at the start ...
+    sol = least_squares(residuals, x0, method="trf", xtol=1e-14, ftol=1e-14, gtol=1e-12, x_scale="jac", max_nfev=400)
+    for _ in range(12):
+        o.optimize(10)
+    chi_o, chi_s = o.chi2()[1], float(np.sum(sol.fun ** 2))
+    assert chi_o < 0.05 * chi_start
+    assert abs(chi_o - chi_s) <= 1e-7 * chi_s, (chi_o, chi_s)          # ... and at the minimum
+    Rs, ts, P = unpack(sol.x)
+    To, po = o.get_poses()[1], o.get_landmarks()[1]
+    for k in range(n_free + 1):
+        assert np.abs(To[k, :9].reshape(3, 3) - Rs[k]).max() < 1e-5 and np.abs(To[k, 9:] - ts[k]).max() < 1e-5
+    n_obs = np.bincount([e[2] for e in edges], minlength=n_lm)
+    assert np.abs(po - P)[n_obs >= 3].max() < 1e-4 and np.abs(po - P).max() < 5e-3   # (one or two inverse-depth sightings: a flat valley)
