@@ -78,17 +78,20 @@ class NativeRccl:
         from . import _capi
         lib = _capi.load_library()
         buf = (C.c_char * 128)()
-        if rank == 0:
-            _capi.check(lib.svi_rccl_unique_id(buf), "svi_rccl_unique_id")
+        failed = None
+        if rank == 0 and lib.svi_rccl_unique_id(buf) != 0:
+            failed = lib.svi_last_error().decode()   # (reported AFTER the exchange: the other ranks are waiting in it)
         raw = bytes(buf)
         if n_ranks > 1:
             if exchange is None:
                 import torch.distributed as dist
-                box = [raw if rank == 0 else None]
+                box = [(None if failed else raw) if rank == 0 else None]
                 dist.broadcast_object_list(box, src=0)
                 raw = box[0]
             else:
-                raw = exchange(raw if rank == 0 else None)
+                raw = exchange((None if failed else raw) if rank == 0 else None)
+        if failed or raw is None:
+            raise RuntimeError("svi_rccl_unique_id failed on rank 0: %s" % (failed or "see rank 0"))
         idb = (C.c_char * 128).from_buffer_copy(raw)
         h = C.c_void_p()
         _capi.check(lib.svi_rccl_create(idb, int(rank), int(n_ranks), int(device), C.byref(h)), "svi_rccl_create")
