@@ -689,6 +689,8 @@ int svi_ba_initialize(svi_ba* ba)
     SVI_HIP(hipStreamSynchronize(ba->stream)); // nothing may still read the buffers that are about to be refilled
     ba->cur = 0;
     ba->have_chi = false;
+    ba->hinv_valid = false;          // (hand-overs between a linearisation and its trial: none is pending across an initialize)
+    ba->lin_post_deferred = false;
     // every edit of the graph's structure clears `initialized`: if it is still set, the device structures are those of this very
     // graph and only the estimates have to go back (g2o rebuilds everything per call; the result is the same)
     if (ba->initialized) return reupload_state(ba);
