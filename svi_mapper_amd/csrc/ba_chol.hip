@@ -139,6 +139,15 @@ constexpr int kPotrfThreads = 512;
 // the three LDS images this needs do not fit beside the factorisation's own (k_trsm stays).
 template <int TS> struct Fold { static constexpr bool on = TS == 48; };
 
+// 16x16 block (r0, c0) of S X' for a LOWER TRIANGULAR X (an inverse of a diagonal factor): X[c][m] = 0 for m > c, so the inner
+// index stops at the block column's last row - 4, 8 or 12 matrix-core steps instead of 12 for the three block columns of a 48 tile
+template <int TS, int LD>
+__device__ __forceinline__ v4f64 mfma_block_tri(const double* sS, int r0, const double* sXinv, int c0)
+{
+    static_assert(TS == 48, "written out for three block columns");
+    return c0 == 0 ? mfma_block<16, LD>(sS, r0, sXinv, c0) : c0 == 16 ? mfma_block<32, LD>(sS, r0, sXinv, c0) : mfma_block<48, LD>(sS, r0, sXinv, c0);
+}
+
 // the 16x16 accumulator block `acc` (row (lane>>4) + 4q, column lane&15) into an LDS image at (r0, c0)
 template <int LD> __device__ __forceinline__ void block_to_lds(const v4f64& acc, double* s, int r0, int c0)
 {
@@ -237,11 +246,20 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
                 tile_load<TS>(Linv_all + (size_t)pre_col(w + 1) * TS * TS, px);
                 if (tid < TS) ypre = y[pre_col(w + 1) * TS + tid];
             }
-            for (int st = wave; st < NB * NB; st += NWV) {
-                const int r0 = (st / NB) * 16, c0 = (st % NB) * 16;
-                const v4f64 lb = mfma_block<TS, LD>(sX, r0, sL, c0);
-                block_to_lds<LD>(lb, sT, r0, c0);
-                block_to_global<TS>(lb, Lout, r0, c0);
+            // nine blocks on eight waves, by cost (block column c needs 4 (c + 1) matrix-core steps): the three of the last
+            // column on waves 0-2, the middle column on waves 3-5, two of the first on wave 6 and one on wave 7 - 12 steps at most
+            {
+                static constexpr signed char kTri[8][2] = {{2, -1}, {5, -1}, {8, -1}, {1, -1}, {4, -1}, {7, -1}, {0, 3}, {6, -1}};
+                static_assert(NB == 3 && NWV == 8, "block assignment of the folded triangular product");
+#pragma unroll
+                for (int u = 0; u < 2; ++u) {
+                    const int st = kTri[wave][u];
+                    if (st < 0) continue;
+                    const int r0 = (st / NB) * 16, c0 = (st % NB) * 16;
+                    const v4f64 lb = mfma_block_tri<TS, LD>(sX, r0, sL, c0);
+                    block_to_lds<LD>(lb, sT, r0, c0);
+                    block_to_global<TS>(lb, Lout, r0, c0);
+                }
             }
             __syncthreads();
 #pragma unroll
@@ -669,7 +687,7 @@ __device__ void gemm_target_block(double* __restrict__ S, double* __restrict__ L
             if (q + 1 < p1) fetch(q + 1);
             for (int st = wave; st < (same ? 1 : 2) * NB * NB; st += NWV) {
                 const int which = st / (NB * NB), bq = st % (NB * NB), r0 = (bq / NB) * 16, c0 = (bq % NB) * 16;
-                const v4f64 lb = mfma_block<TS, LD>(which ? sSb : sSa, r0, sXq, c0);
+                const v4f64 lb = mfma_block_tri<TS, LD>(which ? sSb : sSa, r0, sXq, c0);
                 block_to_lds<LD>(lb, which ? sLb : sLa, r0, c0);
                 if (same) block_to_global<TS>(lb, Lout, r0, c0); // the diagonal target of row i owns L(i,q)
             }
