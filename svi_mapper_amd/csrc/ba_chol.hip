@@ -132,6 +132,10 @@ __device__ __forceinline__ double fast_rsqrt(double x)
 
 constexpr int kPotrfThreads = 512;
 
+// "not computed yet" in the solution vector of the one-launch backward substitution: a NaN with a payload no computation produces
+__device__ __forceinline__ double solve_pending() { return __longlong_as_double(0x7FF8DEADBEEF0001LL); }
+__device__ __forceinline__ bool is_solve_pending(double v) { return __double_as_longlong(v) == 0x7FF8DEADBEEF0001LL; }
+
 // Tile edge 48: the triangular solves of a level (L_ik = S_ik L_kk^-T) are not a launch of their own - every consumer of
 // L_ik in the NEXT level's launch (the chain workgroup that applies it to its diagonal tile, the grouped updates) forms it
 // on the spot from S_ik and L_kk^-1 (a 48^3 product: 27 matrix-core steps), and the one that owns the diagonal target of
@@ -437,7 +441,7 @@ __device__ void gemm_target_block(double* __restrict__ S, double* __restrict__ L
 template <int TS>
 __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict__ S, double* __restrict__ Lt, double* __restrict__ Linv,
                                                              double* __restrict__ g, double* __restrict__ y, int n, double lambda,
-                                                             int* status, int stop_after, StepArgs sa)
+                                                             int* status, int stop_after, StepArgs sa, double* xs)
 {
     constexpr int NB = TS / 16, LD = Lds<TS>::LD;
     extern __shared__ __align__(16) double sm[];
@@ -587,8 +591,10 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
             a3 = fma(sX[tid * LD + c + 3], s_g[c + 3], a3);
         }
         const double yk = (a0 + a1) + (a2 + a3);
-        if (!sa.last_level) y[k * TS + tid] = yk;
-        else s_rs[tid] = yk; // (1/L_jj is no longer needed)
+        if (!sa.last_level) {
+            y[k * TS + tid] = yk;
+            if (xs != y) xs[k * TS + tid] = solve_pending(); // the one-launch backward substitution waits on this value
+        } else s_rs[tid] = yk; // (1/L_jj is no longer needed)
     }
     if (sa.last_level) {
         // the columns of the last level have no rows below them: x_k = L_kk^-T y_k needs nothing else, and the backward
@@ -603,7 +609,7 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
                 a2 = fma(sX[(r + 2) * LD + tid], s_rs[r + 2], a2);
                 a3 = fma(sX[(r + 3) * LD + tid], s_rs[r + 3], a3);
             }
-            y[k * TS + tid] = (a0 + a1) + (a2 + a3);
+            xs[k * TS + tid] = (a0 + a1) + (a2 + a3);
         }
     }
 }
@@ -976,9 +982,114 @@ __global__ __launch_bounds__(kPotrfThreads) void k_back_solve_inl(SolveInline si
     }
 }
 
+// The WHOLE backward substitution in one launch: one workgroup per column below the last level, in descending level order
+// (block index order = dependency order, so a grid larger than the chip holds still makes progress).  A workgroup requests the
+// rows of L_kk^-1, its y_k and every L_ik row it will use right away - none of that depends on another column - and then
+// waits, entry by entry, for the x_i of the rows above: the forward phase left "pending" markers in the solution vector, a
+// marker that disappears IS the hand-over (one remote read per dependency level: 16 hops instead of 16 launches).  Every wait
+// is bounded: a value that never arrives (which would be a defect) ends the kernel with a status instead of hanging the GPU.
+template <int TS>
+__global__ __launch_bounds__(kPotrfThreads) void k_back_solve_all(const SolveRec* __restrict__ recs, const double* __restrict__ Lt,
+                                                                  const double* __restrict__ Linv, const double* __restrict__ y, double* x, int* status)
+{
+    static_assert(TS == 48, "written for the 48-wide tile (one column set per lane)");
+    constexpr int NW = kPotrfThreads / 64, RB = 24, NRB = TS / RB, MAXU = (kInlineSub * NRB + NW - 1) / NW;
+    constexpr int kSpinLimit = 1 << 22;
+    __shared__ double s_part[NW][TS];
+    __shared__ double s_x[NW][RB];
+    __shared__ double s_acc[TS];
+    __shared__ int s_bad;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (*status != 0) return; // (final before this launch: nothing was left pending by a failed factorisation that matters)
+    const SolveRec* rec = recs + blockIdx.x;
+    const int k = rec->k, nq = rec->nq;
+    const int c0 = lane < TS ? lane : TS - 1;
+    constexpr int RW = (TS + NW - 1) / NW;
+    double xv0[RW];
+    {
+        const double* X = Linv + (size_t)k * TS * TS;
+#pragma unroll
+        for (int rr = 0; rr < RW; ++rr) {
+            const int r = wave * RW + rr < TS ? wave * RW + rr : TS - 1;
+            xv0[rr] = X[r * TS + c0];
+        }
+    }
+    if (tid == 0) s_bad = 0;
+    double lv[MAXU][RB];
+    const double* xsrc[MAXU];
+#pragma unroll
+    for (int s = 0; s < MAXU; ++s) {
+        const int u = wave + NW * s;
+        xsrc[s] = nullptr;
+#pragma unroll
+        for (int w = 0; w < RB; ++w) lv[s][w] = 0.0;
+        if (u < nq * NRB) { // uniform
+            const int q = u / NRB, rb = u % NRB;
+            const double* L = Lt + (size_t)rec->tile[q] * TS * TS + (size_t)rb * RB * TS;
+            xsrc[s] = x + (size_t)rec->row[q] * TS + rb * RB + (lane < RB ? lane : 0);
+#pragma unroll
+            for (int w = 0; w < RB; ++w) lv[s][w] = L[w * TS + c0];
+        }
+    }
+    const double yk = tid < TS ? y[k * TS + tid] : 0.0;
+    double a0 = 0.0, a0b = 0.0;
+    bool bad = false;
+#pragma unroll
+    for (int s = 0; s < MAXU; ++s) {
+        if (wave + NW * s >= nq * NRB) break; // uniform
+        double xin = 0.0;
+        if (lane < RB) {
+            int spins = 0;
+            do { xin = __hip_atomic_load(xsrc[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (is_solve_pending(xin) && ++spins < kSpinLimit);
+            bad = bad || is_solve_pending(xin);
+        }
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (lane < RB) s_x[wave][lane] = xin;
+        asm volatile("" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int w = 0; w < RB; w += 2) { // two chains per column: the FMAs are latency-bound
+            a0 = fma(lv[s][w], s_x[wave][w], a0);
+            a0b = fma(lv[s][w + 1], s_x[wave][w + 1], a0b);
+        }
+    }
+    if (bad) s_bad = 1;
+    if (lane < TS) s_part[wave][lane] = a0 + a0b;
+    __syncthreads();
+    if (s_bad) { if (tid == 0) atomicCAS(status, 0, -3); return; } // (the pending markers of this column stay: the columns below end the same way)
+    if (tid < TS) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += s_part[w][tid];
+        s_acc[tid] = yk - sum;
+    }
+    __syncthreads();
+    double b0[2] = {0.0, 0.0};
+#pragma unroll
+    for (int rr = 0; rr < RW; ++rr) {
+        const int r = wave * RW + rr;
+        const double sr = r < TS ? s_acc[r < TS ? r : 0] : 0.0;
+        b0[rr & 1] = fma(r >= c0 ? xv0[rr] : 0.0, sr, b0[rr & 1]); // Linv is lower triangular
+    }
+    __syncthreads(); // (s_part is reused)
+    if (lane < TS) s_part[wave][lane] = b0[0] + b0[1];
+    __syncthreads();
+    if (tid < TS) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += s_part[w][tid];
+        __hip_atomic_store(x + k * TS + tid, sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 template <int TS>
 int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n, int* status, hipStream_t s)
 {
+    // one-launch backward substitution (tile 48, every column's list short enough): the forward vector then lives in p.ybuf and
+    // the solution vector carries "pending" markers until its entries are computed
+    const bool one_launch = TS == 48 && p.solve_recs != nullptr && p.n_solve_cols > 0 && p.ybuf != nullptr;
+    double* const yv = one_launch ? p.ybuf : x;
     constexpr int LD = Lds<TS>::LD, Q = TS / kOB;
     const size_t lds_p = sizeof(double) * (Fold<TS>::on ? 5 : 2) * (size_t)TS * LD; // folded: the grouped updates stage five images
     constexpr int kTB = TrsmBlock<TS>::TB, QT = TS / kTB;
@@ -1001,9 +1112,15 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
         sa.n_chain = nc; sa.last_level = st == p.n_steps - 1; sa.chain_col = p.step_col + c0; sa.chain_desc = reinterpret_cast<const int4*>(p.step_desc) + 2 * c0;
         sa.tgt_tile = p.tgt_tile + t0; sa.tgt_row = p.tgt_row + t0; sa.tgt_pair_ptr = p.tgt_pair_ptr + t0;
         if (p.h_chain_inl) sa.inl = p.h_chain_inl[st]; else sa.inl.n = 0;
-        hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(nc + ntg * Q * Q), dim3(kPotrfThreads), lds_p, s, S, Lt, Linv, g, x, n, lambda, status, 0, sa);
+        hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(nc + ntg * Q * Q), dim3(kPotrfThreads), lds_p, s, S, Lt, Linv, g, yv, n, lambda, status, 0, sa, x);
         const int i0 = p.h_trsm_ptr[st], ni = p.h_trsm_ptr[st + 1] - i0;
         if (ni > 0 && !Fold<TS>::on) hipLaunchKernelGGL(k_trsm<TS>, dim3(ni * QT * QT), dim3(kBlock), lds_g, s, S, Lt, Linv, p.st_tile + i0, p.st_col + i0, status);
+    }
+    if constexpr (TS == 48) {
+        if (one_launch) {
+            hipLaunchKernelGGL(k_back_solve_all<TS>, dim3(p.n_solve_cols), dim3(kPotrfThreads), 0, s, p.solve_recs, Lt, Linv, yv, x, status);
+            return 0;
+        }
     }
     for (int st = p.n_steps - 2; st >= 0; --st) { // (the last level solved its x inside k_potrf_inv)
         const int c0 = p.h_step_ptr[st], nc = p.h_step_ptr[st + 1] - c0;
@@ -1043,9 +1160,9 @@ static int potrf_probe(int reps, int stop_after, double* ms_out)
     (void)hipMemset(g, 0, sizeof(double) * TS); (void)hipMemset(st, 0, sizeof(int));
     hipEvent_t a, b;
     (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(1), dim3(kPotrfThreads), lds_p, 0, S, L, X, g, y, TS, 0.0, st, stop_after, sa);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(1), dim3(kPotrfThreads), lds_p, 0, S, L, X, g, y, TS, 0.0, st, stop_after, sa, y);
     (void)hipEventRecord(a, 0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(1), dim3(kPotrfThreads), lds_p, 0, S, L, X, g, y, TS, 0.0, st, stop_after, sa);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(1), dim3(kPotrfThreads), lds_p, 0, S, L, X, g, y, TS, 0.0, st, stop_after, sa, y);
     (void)hipEventRecord(b, 0);
     (void)hipEventSynchronize(b);
     float ms = 0.f;

@@ -176,6 +176,10 @@ struct CholPlan {
     // host: the same per level as kernel arguments (n = 0 where a level does not fit)
     const ChainInline* h_chain_inl = nullptr; // [n_steps]
     const SolveInline* h_solve_inl = nullptr; // [n_steps]
+    // one-launch backward substitution: a record per column below the last level, highest level first; the forward vector
+    const SolveRec* solve_recs = nullptr;    // device
+    int n_solve_cols = 0;                    // 0: not available (a column with more than kInlineSub tiles, or another tile size)
+    double* ybuf = nullptr;                  // device, [NT * TS]
 };
 
 

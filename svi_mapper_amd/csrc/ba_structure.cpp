@@ -1007,6 +1007,27 @@ int upload(Build& b)
             ba->solve_inl[st].n = solve_ok ? nc : 0;
         }
         p.h_chain_inl = ba->chain_inl.data(); p.h_solve_inl = ba->solve_inl.data();
+        {   // the same records once more, for the one-launch backward substitution: levels n_steps-2 .. 0, a column per workgroup
+            std::vector<SolveRec> recs;
+            bool ok = TS == 48 && b.n_steps >= 2;
+            for (int st = b.n_steps - 2; st >= 0 && ok; --st)
+                for (int q = b.h_step_ptr[st]; q < b.h_step_ptr[st + 1]; ++q) {
+                    const int c = b.step_col[q], nq = b.h_col_ptr[c + 1] - b.h_col_ptr[c];
+                    if (nq > kInlineSub) { ok = false; break; }
+                    SolveRec r{};
+                    r.k = c; r.nq = nq;
+                    for (int w = 0; w < nq; ++w) { r.tile[w] = b.trsm_tile[b.h_col_ptr[c] + w]; r.row[w] = b.trsm_row[b.h_col_ptr[c] + w]; }
+                    recs.push_back(r);
+                }
+            p.solve_recs = nullptr; p.n_solve_cols = 0; p.ybuf = nullptr;
+            if (ok && !recs.empty() && recs.size() <= 1024) {
+                SVI_TRY(up.up(recs, &p.solve_recs));
+                p.n_solve_cols = (int)recs.size();
+                double* yb = nullptr;
+                SVI_TRY(up.alloc((size_t)NT * TS, &yb));
+                p.ybuf = yb;
+            }
+        }
         SVI_TRY(up.up(b.diag_tile, &p.diag_tile));
         SVI_TRY(up.up(b.pre_ptr, &p.pre_ptr));
         SVI_TRY(up.up(b.pre_tile, &p.pre_tile));
