@@ -792,30 +792,57 @@ int schur_work_lists(Build& b)
     int n_cu = 256;
     if (const int cu = device_compute_units(ba->opt.device)) n_cu = cu;
     const int64_t qj_cap = (int64_t)4 * (n_cu * 4 * 2);
-    auto pieces = [&](int len) { int64_t cnt = 0; for (int c = 0; c < n_cells; ++c) cnt += (cell_ptr[c + 1] - cell_ptr[c] + len - 1) / len; return cnt; };
+    // XCD-aware placement.  Workgroups b and b + 8 share an XCD (its 4 MiB L2); an edge's operands are wanted by every cell of
+    // its pose group's ROW (as row segment) and COLUMN (as column segment), 7-9 items in as many cells at config 4.  Dealt
+    // round-robin, those cells end up on all eight XCDs and each of them fetches the edge over the fabric (700 MB per launch
+    // against 77 MB of operands).  So the rows of cells are cut into eight contiguous ranges of equal work, one per XCD:
+    // the row-segment re-reads all hit that XCD's L2, the column-segment re-reads mostly (band width < range width).
+    constexpr int NX = 8;
+    const int NG = 2 * NSUB; // row groups of four poses
+    auto row_group = [&](int c) { return 2 * b.sub_cx[c / 4] + (c / 2) % 2; };
+    std::vector<int> grp_pieces((size_t)NG), grp_x((size_t)NG);
     int L = 16;
-    while (L < 1024 && pieces(L) > qj_cap) ++L;
+    for (;; ++L) {
+        std::fill(grp_pieces.begin(), grp_pieces.end(), 0);
+        int64_t total = 0;
+        for (int c = 0; c < n_cells; ++c) { const int k = (cell_ptr[c + 1] - cell_ptr[c] + L - 1) / L; grp_pieces[row_group(c)] += k; total += k; }
+        // contiguous ranges of row groups with about total / NX pieces each
+        int64_t acc = 0, worst = 0, in_x = 0;
+        int x = 0;
+        for (int g = 0; g < NG; ++g) {
+            if (x < NX - 1 && in_x > 0 && (acc + grp_pieces[g] / 2) * NX > total * (x + 1)) { worst = std::max(worst, in_x); in_x = 0; ++x; }
+            grp_x[g] = x; acc += grp_pieces[g]; in_x += grp_pieces[g];
+        }
+        worst = std::max(worst, in_x);
+        if (L >= 1024 || (total <= qj_cap && worst <= qj_cap / NX)) break;
+    }
     struct QJob { int begin, end, cell; };
     std::vector<QJob> qjobs;
     for (int c = 0; c < n_cells; ++c)
         for (int i = cell_ptr[c]; i < cell_ptr[c + 1]; i += L) qjobs.push_back({i, std::min(i + L, cell_ptr[c + 1]), c});
-    // waves take four quarter jobs of similar length; the slabs of a cell are summed in the order of its pieces
-    std::vector<int> qorder(qjobs.size());
-    for (size_t i = 0; i < qorder.size(); ++i) qorder[i] = (int)i;
-    std::stable_sort(qorder.begin(), qorder.end(), [&](int x, int y) { return qjobs[x].end - qjobs[x].begin > qjobs[y].end - qjobs[y].begin; });
-    b.n_jobs = ((int)qjobs.size() + 3) / 4;
+    // inside an XCD waves take four quarter jobs of similar length; the slabs of a cell are summed in the order of its pieces
+    std::vector<int> xq[NX];
+    for (size_t i = 0; i < qjobs.size(); ++i) xq[grp_x[row_group(qjobs[i].cell)]].push_back((int)i);
+    int nblk = 0;
+    for (int x = 0; x < NX; ++x) {
+        std::stable_sort(xq[x].begin(), xq[x].end(), [&](int u, int v) { return qjobs[u].end - qjobs[u].begin > qjobs[v].end - qjobs[v].begin; });
+        nblk = std::max(nblk, ((int)xq[x].size() + 15) / 16);
+    }
+    b.n_jobs = NX * nblk * 4; // workgroup 8 i + x = the i-th group of sixteen quarter jobs of XCD x (empty ones pad the short lists)
     const size_t nq4 = (size_t)4 * std::max(b.n_jobs, 1);
     b.qj_begin.assign(nq4, 0); b.qj_end.assign(nq4, 0); b.qj_diag.assign(nq4, 0);
     b.job_len.assign(std::max(b.n_jobs, 1), 0);
     std::vector<int> slot_of(qjobs.size(), -1);
-    for (size_t k = 0; k < qorder.size(); ++k) {
-        const QJob& q = qjobs[qorder[k]];
-        b.qj_begin[k] = q.begin; b.qj_end[k] = q.end;
-        const int sub = q.cell / 4, u = (q.cell / 2) % 2, v = q.cell % 2;
-        b.qj_diag[k] = (b.sub_cx[sub] == b.sub_cy[sub] && u == v) ? 1 : 0;
-        b.job_len[k / 4] = std::max(b.job_len[k / 4], q.end - q.begin);
-        slot_of[qorder[k]] = (int)k;
-    }
+    for (int x = 0; x < NX; ++x)
+        for (size_t j = 0; j < xq[x].size(); ++j) {
+            const QJob& q = qjobs[xq[x][j]];
+            const size_t k = ((size_t)(NX * (j / 16) + x) * 4 + (j / 4) % 4) * 4 + j % 4;
+            b.qj_begin[k] = q.begin; b.qj_end[k] = q.end;
+            const int sub = q.cell / 4, u = (q.cell / 2) % 2, v = q.cell % 2;
+            b.qj_diag[k] = (b.sub_cx[sub] == b.sub_cy[sub] && u == v) ? 1 : 0;
+            b.job_len[k / 4] = std::max(b.job_len[k / 4], q.end - q.begin);
+            slot_of[xq[x][j]] = (int)k;
+        }
     b.cell_qj_ptr.assign((size_t)n_cells + 1, 0);
     {
         size_t k = 0;
