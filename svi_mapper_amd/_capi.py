@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libsvi_hot.so")
+LIB_PATH = os.environ.get("SVI_HOT_LIB") or os.path.join(_HERE, "lib", "libsvi_hot.so")   # (the override is for A/B timing of builds)
 
 SVI_OK = 0
 SVI_PH_NAMES = ("linearize_lm", "linearize_pose", "pose_edges", "schur", "assemble", "allreduce",

@@ -795,6 +795,9 @@ __global__ __launch_bounds__(kBlock) void k_finalize_invert(BaDev d, const int* 
 // g_i += (W_a Hinv_l) b_l.  The kernel is FP64-instruction bound: four-pose cells give 61 % of the
 // lanes work at KITTI-like co-visibility where eight-pose cells gave 36 %.
 // ---------------------------------------------------------------------------------------------
+#ifndef SCHUR_ABL
+#define SCHUR_ABL 0
+#endif
 constexpr int kSchurBatch = 2;        // passes (one item per quarter) staged per wave and buffer
 constexpr int kSchurSlot  = 115;      // doubles per staged item: 8 edge slots x (N 9, Z 3), Hinv(6), b_l(3), pad; odd
                                       // multiple chosen so that the 16 (quarter, pose) operand rows sit in 16 different bank pairs
@@ -887,7 +890,9 @@ __global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
 #pragma unroll
         for (int t = 0; t < kSchurBatch; ++t) mk[t] = st.m[t];
         if (base + kSchurBatch < n_pass) {
+#if SCHUR_ABL != 2
             schur_fetch(d, pk, diag, lane, st);
+#endif
             schur_fetch_items(items, it0, it1, base + 2 * kSchurBatch, pk);
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -899,6 +904,9 @@ __global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
             const bool active = ((mI >> i) & 1u) && ((mJ >> j) & 1u) && (!diag || i >= j);
             if (!active) continue;
             const double* slot = s_stage[wave][buf][t][qt];
+#if SCHUR_ABL == 1
+            acc[0] += slot[12 * __popc(mI & below_i)] + slot[96]; continue;
+#endif
             const double* na = slot + 12 * __popc(mI & below_i);
             const double* nbp = slot + 12 * (diag ? __popc(mJ & below_j) : 4 + __popc(mJ & below_j));
             const double* Hi = slot + 96;

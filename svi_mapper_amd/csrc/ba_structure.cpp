@@ -825,7 +825,13 @@ int schur_work_lists(Build& b)
     for (size_t i = 0; i < qjobs.size(); ++i) xq[grp_x[row_group(qjobs[i].cell)]].push_back((int)i);
     int nblk = 0;
     for (int x = 0; x < NX; ++x) {
-        std::stable_sort(xq[x].begin(), xq[x].end(), [&](int u, int v) { return qjobs[u].end - qjobs[u].begin > qjobs[v].end - qjobs[v].begin; });
+        // diagonal cells first: their waves carry the right-hand side (and skip the column segment), the others do neither
+        auto is_diag = [&](int q) { const int c = qjobs[q].cell, sub = c / 4; return b.sub_cx[sub] == b.sub_cy[sub] && (c / 2) % 2 == c % 2; };
+        std::stable_sort(xq[x].begin(), xq[x].end(), [&](int u, int v) {
+            const bool du = is_diag(u), dv = is_diag(v);
+            if (du != dv) return du;
+            return qjobs[u].end - qjobs[u].begin > qjobs[v].end - qjobs[v].begin;
+        });
         nblk = std::max(nblk, ((int)xq[x].size() + 15) / 16);
     }
     b.n_jobs = NX * nblk * 4; // workgroup 8 i + x = the i-th group of sixteen quarter jobs of XCD x (empty ones pad the short lists)
