@@ -167,6 +167,19 @@ template <int TS> __device__ __forceinline__ void block_to_global(const v4f64& a
     for (int q = 0; q < 4; ++q) g[(size_t)(r0 + (lane >> 4) + 4 * q) * TS + c0 + (lane & 15)] = acc[q];
 }
 
+// Block ownership and work tables of the factorisation workgroup, packed into 32-bit literals (a nibble per wave, value + 1):
+// indexed as arrays they are loads from the constant section, i.e. a memory round trip in front of the operand loads whose
+// addresses depend on them (seen in the ISA: 0.4 us per level).
+constexpr signed char kOwn6T[8][3][2] = {{{5, 5}, {4, 3}, {3, 1}}, {{5, 4}, {3, 3}, {2, 1}}, {{4, 4}, {5, 2}, {1, 1}},
+                                         {{5, 3}, {4, 2}, {5, 0}}, {{3, 2}, {4, 0}, {0, 0}}, {{2, 2}, {3, 0}, {-1, -1}},
+                                         {{5, 1}, {2, 0}, {-1, -1}}, {{4, 1}, {1, 0}, {-1, -1}}};
+constexpr signed char kOwn3T[8][2] = {{2, 2}, {2, 1}, {1, 1}, {2, 0}, {1, 0}, {0, 0}, {-1, -1}, {-1, -1}};
+constexpr signed char kTriT[8][2] = {{2, -1}, {5, -1}, {8, -1}, {1, -1}, {4, -1}, {7, -1}, {0, 3}, {6, -1}};
+constexpr unsigned pack_own6(int u, int ab) { unsigned v = 0; for (int w = 0; w < 8; ++w) v |= (unsigned)(kOwn6T[w][u][ab] + 1) << (4 * w); return v; }
+constexpr unsigned pack_own3(int ab) { unsigned v = 0; for (int w = 0; w < 8; ++w) v |= (unsigned)(kOwn3T[w][ab] + 1) << (4 * w); return v; }
+constexpr unsigned pack_tri(int u) { unsigned v = 0; for (int w = 0; w < 8; ++w) v |= (unsigned)(kTriT[w][u] + 1) << (4 * w); return v; }
+__device__ __forceinline__ int unpack_nibble(unsigned packed, int wave) { return (int)((packed >> (4 * wave)) & 0xFu) - 1; }
+
 // ---------------------------------------------------------------------------------------------
 // potrf + inverse + y_k of one diagonal tile, 512 threads.  The right-looking sweep eliminates FOUR columns per
 // barrier (the 4x4 pivot block is factorised redundantly by every lane) and keeps the tile in MFMA accumulator
@@ -183,13 +196,16 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
                                                  double* __restrict__ y, double* __restrict__ Lt, const int* __restrict__ pre_tile_g,
                                                  const int* __restrict__ pre_col_g, int npre, double* s_g, const double* __restrict__ S_all,
                                                  const double* __restrict__ Linv_all, double* sT, const int* __restrict__ status,
-                                                 bool use_inl, int it0, int it1, int ic0, int ic1)
+                                                 int it0, int it1, int ic0, int ic1, double gk)
 {
     // the status word goes first, the operand tiles right behind it: the test waits for its own load only
     const int failed_before = *status;
+    // The first two pending sources arrive as values (kernel arguments, or read by the caller with the column record): a
+    // conditional index load in front of the tile loads is a join point where the compiler has to wait for EVERY load in
+    // flight (the counter cannot tell them apart) - the operand tiles then arrived one round trip after the other.
     static_assert(kInlinePre == 2, "the inline record is selected without indexing");
-    auto pre_tile = [=](int w) { return use_inl ? (w == 0 ? it0 : it1) : pre_tile_g[w]; };
-    auto pre_col = [=](int w) { return use_inl ? (w == 0 ? ic0 : ic1) : pre_col_g[w]; };
+    auto pre_tile = [=](int w) { return w == 0 ? it0 : w == 1 ? it1 : pre_tile_g[w]; };
+    auto pre_col = [=](int w) { return w == 0 ? ic0 : w == 1 ? ic1 : pre_col_g[w]; };
     constexpr int kOk = 0, kNotPositive = 1, kAborted = 2;
     constexpr int NB = TS / 16, LD = Lds<TS>::LD, KB = 4;
     constexpr int NBLK = NB * (NB + 1) / 2, NWV = kPotrfThreads / 64, PER = (NBLK + NWV - 1) / NWV;
@@ -202,24 +218,18 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
     // with an older wave issue behind it (measured: 480 vs 795 cycles per quad), and a block is live only while its
     // block column has not been passed: the tables give the long-lived blocks to the fast waves and the slow waves
     // one block less, from a greedy search over per-quad cost = chain(wave) + 250 x live blocks (tools note in DESIGN).
-    static constexpr signed char kOwn6[8][3][2] = {{{5, 5}, {4, 3}, {3, 1}}, {{5, 4}, {3, 3}, {2, 1}}, {{4, 4}, {5, 2}, {1, 1}},
-                                                   {{5, 3}, {4, 2}, {5, 0}}, {{3, 2}, {4, 0}, {0, 0}}, {{2, 2}, {3, 0}, {-1, -1}},
-                                                   {{5, 1}, {2, 0}, {-1, -1}}, {{4, 1}, {1, 0}, {-1, -1}}};
-    static constexpr signed char kOwn3[8][1][2] = {{{2, 2}}, {{2, 1}}, {{1, 1}}, {{2, 0}}, {{1, 0}}, {{0, 0}}, {{-1, -1}}, {{-1, -1}}};
     static_assert((NB == 6 && PER == 3) || (NB == 3 && PER == 1), "block ownership tables exist for 96 and 48 wide tiles");
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-        const int ta = NB == 6 ? kOwn6[wave][u < 3 ? u : 0][0] : kOwn3[wave][0][0];
-        const int tb = NB == 6 ? kOwn6[wave][u < 3 ? u : 0][1] : kOwn3[wave][0][1];
+        const int ta = unpack_nibble(NB == 6 ? pack_own6(u < 3 ? u : 0, 0) : pack_own3(0), wave);
+        const int tb = unpack_nibble(NB == 6 ? pack_own6(u < 3 ? u : 0, 1) : pack_own3(1), wave);
         own[u] = ta >= 0;
         ba[u] = own[u] ? ta : 0;
         bb[u] = own[u] ? tb : 0;
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = 16 * ba[u] + lk + 4 * q, c = 16 * bb[u] + ln;
-            double v = own[u] ? A[r * TS + c] : 0.0;
-            if (own[u] && r == c && k * TS + r < n) v += lambda; // g2o setLambda: H_jj += lambda on real rows
-            acc[u][q] = v;
+            acc[u][q] = own[u] ? A[r * TS + c] : 0.0; // (lambda goes on below: nothing may consume this load before the others are issued)
         }
     }
     // pending updates of this tile from the columns of the level just below: A -= L(k,q) L(k,q)' and the forward
@@ -253,11 +263,10 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
             // nine blocks on eight waves, by cost (block column c needs 4 (c + 1) matrix-core steps): the three of the last
             // column on waves 0-2, the middle column on waves 3-5, two of the first on wave 6 and one on wave 7 - 12 steps at most
             {
-                static constexpr signed char kTri[8][2] = {{2, -1}, {5, -1}, {8, -1}, {1, -1}, {4, -1}, {7, -1}, {0, 3}, {6, -1}};
-                static_assert(NB == 3 && NWV == 8, "block assignment of the folded triangular product");
+                static_assert(NB == 3 && NWV == 8, "block assignment of the folded triangular product (kTriT)");
 #pragma unroll
                 for (int u = 0; u < 2; ++u) {
-                    const int st = kTri[wave][u];
+                    const int st = unpack_nibble(pack_tri(u), wave);
                     if (st < 0) continue;
                     const int r0 = (st / NB) * 16, c0 = (st % NB) * 16;
                     const v4f64 lb = mfma_block_tri<TS, LD>(sX, r0, sL, c0);
@@ -278,7 +287,7 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
                     a2 = fma(sT[tid * LD + m + 2], s_rs[m + 2], a2);
                     a3 = fma(sT[tid * LD + m + 3], s_rs[m + 3], a3);
                 }
-                s_g[tid] -= (a0 + a1) + (a2 + a3);
+                gk -= (a0 + a1) + (a2 + a3);
             }
             __syncthreads();
         }
@@ -305,15 +314,21 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
                 a2 = fma(sL[tid * LD + m + 2], s_rs[m + 2], a2);
                 a3 = fma(sL[tid * LD + m + 3], s_rs[m + 3], a3);
             }
-            s_g[tid] -= (a0 + a1) + (a2 + a3);
+            gk -= (a0 + a1) + (a2 + a3);
         }
         __syncthreads();
     }
     }
+    if (tid < TS) s_g[tid] = gk; // g_k minus the pending sources: read again when y_k is formed, many barriers from here
 #pragma unroll
     for (int u = 0; u < PER; ++u)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[u][q] -= accU[u][q];
+        for (int q = 0; q < 4; ++q) {
+            const int r = 16 * ba[u] + lk + 4 * q, c = 16 * bb[u] + ln;
+            double v = acc[u][q];
+            if (own[u] && r == c && k * TS + r < n) v += lambda; // g2o setLambda: H_jj += lambda on real rows
+            acc[u][q] = v - accU[u][q];
+        }
     if (stop_after == 5) { if (tid < TS) y[k * TS + tid] = acc[0][0]; return kOk; }
     long long t_clk0 = 0, t_rt0 = 0;
     const bool probe = stop_after >= 6 && stop_after <= 9;
@@ -467,13 +482,27 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
     ChainRec rec = sa.inl.c[0]; // (selected with constant indices: indexing the argument would move it to scratch memory)
 #pragma unroll
     for (int i = 1; i < kInlineCols; ++i) if ((int)blockIdx.x == i) rec = sa.inl.c[i];
+    int it0 = rec.pre_tile[0], it1 = rec.pre_tile[1], ic0 = rec.pre_col[0], ic1 = rec.pre_col[1];
     if (inl) { k = rec.k; tile_id = rec.tile; npre = rec.npre; }
-    else { const int4 ds = sa.chain_desc[2 * (int)blockIdx.x]; k = ds.x; tile_id = ds.y; pre0 = ds.z; npre = ds.w; }
+    else {
+        const int4 ds = sa.chain_desc[2 * (int)blockIdx.x];
+        k = __builtin_amdgcn_readfirstlane(ds.x); tile_id = __builtin_amdgcn_readfirstlane(ds.y);
+        pre0 = __builtin_amdgcn_readfirstlane(ds.z); npre = __builtin_amdgcn_readfirstlane(ds.w);
+        // (read to scalar registers INSIDE this branch: a vector register that may or may not have a load pending at the join
+        // makes the compiler wait, at its first use, for everything issued in between - on the inline path as well)
+        const int a0 = npre > 0 ? sa.pre_tile[pre0] : 0, b0 = npre > 0 ? sa.pre_col[pre0] : 0;
+        const int a1 = npre > 1 ? sa.pre_tile[pre0 + 1] : 0, b1 = npre > 1 ? sa.pre_col[pre0 + 1] : 0;
+        it0 = __builtin_amdgcn_readfirstlane(a0); ic0 = __builtin_amdgcn_readfirstlane(b0);
+        it1 = __builtin_amdgcn_readfirstlane(a1); ic1 = __builtin_amdgcn_readfirstlane(b1);
+    }
     const double* A = S + (size_t)tile_id * TS * TS;
     double* Lg = Lt + (size_t)tile_id * TS * TS;
-    if (tid < TS) s_g[tid] = g[k * TS + tid];
+    // g_k is requested here and parked in LDS by the sweep once the operand tiles are on their way (a store to LDS right here
+    // would wait for this load alone: one memory round trip in front of all the others)
+    double gk = 0.0;
+    if (tid < TS) gk = g[k * TS + tid];
     const int rc = potrf_sweep_mfma<TS>(A, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y, Lt, sa.pre_tile + pre0, sa.pre_col + pre0, npre, s_g, S,
-                                        Linv, sm + 2 * TS * LD, status, inl, rec.pre_tile[0], rec.pre_tile[1], rec.pre_col[0], rec.pre_col[1]);
+                                        Linv, sm + 2 * TS * LD, status, it0, it1, ic0, ic1, gk);
     if (rc == 2) return;                                  // an earlier column of this trial had failed
     if (rc == 1) { if (tid == 0) *status = k + 1; return; } // not positive definite
     if (stop_after == 5 || (stop_after >= 6 && stop_after <= 9) || stop_after == 1) return;
