@@ -30,6 +30,15 @@ constexpr int kBlock = 256;
 constexpr int kOB = 48; // output block edge of the trsm / gemm workgroups
 typedef double v4f64 __attribute__((ext_vector_type(4)));
 
+// -DPOTRF_TS: shader-clock stamps of the first chain workgroup of every level (phase boundaries of k_potrf_inv), printed by
+// run() at its 100th call - how the per-phase figures in DESIGN.md were measured.  Compiled out otherwise.
+#ifdef POTRF_TS
+__device__ unsigned long long g_ts[64 * 12];
+__device__ int g_ts_cnt, g_ts_cur;
+#define TS_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_ts[g_ts_cur * 12 + (i)] = clock64(); } while (0)
+#else
+#define TS_MARK(i) do { } while (0)
+#endif
 template <int TS> struct Lds { static constexpr int LD = TS + 2; }; // (TS+2) % 32 == 2: conflict-free ds_read_b64 of MFMA operands
 
 // rows [r0, r0+NR) of a TS x TS row-major global tile -> LDS (row stride LD)
@@ -196,7 +205,7 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
                                                  double* __restrict__ y, double* __restrict__ Lt, const int* __restrict__ pre_tile_g,
                                                  const int* __restrict__ pre_col_g, int npre, double* s_g, const double* __restrict__ S_all,
                                                  const double* __restrict__ Linv_all, double* sT, const int* __restrict__ status,
-                                                 int it0, int it1, int ic0, int ic1, double gk)
+                                                 int it0, int it1, int ic0, int ic1, double gk, double* s_cf)
 {
     // the status word goes first, the operand tiles right behind it: the test waits for its own load only
     const int failed_before = *status;
@@ -254,6 +263,7 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
             tile_store<TS>(px, sL);
             if (tid < TS) s_rs[tid] = ypre;
             __syncthreads();
+            TS_MARK(1); // operands in LDS
             double* Lout = Lt + (size_t)pre_tile(w) * TS * TS;
             if (w + 1 < npre) { // the next source travels while this one is multiplied
                 tile_load<TS>(S_all + (size_t)pre_tile(w + 1) * TS * TS, ps);
@@ -275,6 +285,7 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
                 }
             }
             __syncthreads();
+            TS_MARK(2); // L(k,q) formed
 #pragma unroll
             for (int u = 0; u < PER; ++u)
                 if (own[u]) accU[u] = mfma_block_acc<TS, LD>(sT, 16 * ba[u], sT, 16 * bb[u], accU[u]);
@@ -290,6 +301,7 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
                 gk -= (a0 + a1) + (a2 + a3);
             }
             __syncthreads();
+            TS_MARK(3); // pending update applied
         }
     } else {
     TileRegs<TS> pre;
@@ -333,6 +345,7 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
     long long t_clk0 = 0, t_rt0 = 0;
     const bool probe = stop_after >= 6 && stop_after <= 9;
     if (probe) { t_clk0 = clock64(); t_rt0 = wall_clock64(); }
+    TS_MARK(4);
     bool fail = false;
     // (A look-ahead variant - next quad's block column updated and published first, the next pivot chain and the other
     // blocks behind the same barrier, the two waves of a SIMD in opposite order - is correct but measured 33 us per
@@ -397,11 +410,16 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
             if (tid == 0) {
 #pragma unroll
                 for (int m = 0; m < KB; ++m) s_rs[j + m] = w[m][m];
+                // the inverse of the quad's unit factor is the 4x4 diagonal block of L^-1 up to the row scaling: kept for the
+                // inversion stage (which then starts at 4 -> 8)
+                double2* cf = reinterpret_cast<double2*>(s_cf + 6 * (j / KB));
+                cf[0] = make_double2(c10, c20); cf[1] = make_double2(c21, c30); cf[2] = make_double2(c31, c32);
             }
         }
         if (fail) break;
     }
     __syncthreads();
+    TS_MARK(5); // pivot sweep done
     if (fail) return kNotPositive;
     if (probe) { // shader cycles and 100 MHz ticks spent in the pivot sweep
         if (tid == 0) { y[0] = (double)(clock64() - t_clk0); y[1] = (double)(wall_clock64() - t_rt0); y[2] = acc[0][0]; }
@@ -423,6 +441,18 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
                 if (c <= r) sL[r * LD + c] = acc[u][q] * s_rs[c];
             }
         }
+    // X = L^-1, first stage: the 4x4 diagonal blocks.  L_qq = Lu D^1/2 with the quad's unit factor Lu, so
+    // L_qq^-1 = D^-1/2 Lu^-1 - Lu^-1 is what the sweep solved its panels with (c10 .. c32 above).
+    if (tid < TS) {
+        const int o = (tid >> 2) * 4, c = tid & 3;
+        const double* cf = s_cf + 6 * (tid >> 2);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const double v = r < c ? 0.0 : r == c ? 1.0 : cf[r * (r - 1) / 2 + c];
+            sX[(o + r) * LD + o + c] = v * s_rs[o + r];
+        }
+    }
+    TS_MARK(6); // L image, 4x4 inverses
     return kOk;
 }
 
@@ -467,9 +497,14 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
     __shared__ __align__(16) double s_buf[kScratch];
     __shared__ double s_rs[TS];        // 1/sqrt(d_j) = 1/L_jj
     __shared__ double s_g[TS];
+    __shared__ __align__(16) double s_cf[(TS / 4) * 6]; // Lu^-1 of every quad (below the diagonal)
     static_assert(sizeof(double) * (2 * TS * LD + kScratch + 2 * TS) <= 160 * 1024, "potrf LDS budget (160 KiB per workgroup)");
     double (*s_col)[TS][4] = reinterpret_cast<double (*)[TS][4]>(s_buf);
     const int tid = threadIdx.x;
+#ifdef POTRF_TS
+    if (tid == 0 && blockIdx.x == 0) g_ts_cur = atomicAdd(&g_ts_cnt, 1) & 63;
+#endif
+    TS_MARK(0);
     if ((int)blockIdx.x >= sa.n_chain) {
         if (*status != 0) return;
         gemm_target_block<TS>(S, Lt, Linv, sa, (int)blockIdx.x - sa.n_chain, g, y, sm);
@@ -502,70 +537,53 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
     double gk = 0.0;
     if (tid < TS) gk = g[k * TS + tid];
     const int rc = potrf_sweep_mfma<TS>(A, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y, Lt, sa.pre_tile + pre0, sa.pre_col + pre0, npre, s_g, S,
-                                        Linv, sm + 2 * TS * LD, status, it0, it1, ic0, ic1, gk);
+                                        Linv, sm + 2 * TS * LD, status, it0, it1, ic0, ic1, gk, s_cf);
     if (rc == 2) return;                                  // an earlier column of this trial had failed
     if (rc == 1) { if (tid == 0) *status = k + 1; return; } // not positive definite
     if (stop_after == 5 || (stop_after >= 6 && stop_after <= 9) || stop_after == 1) return;
     __syncthreads();
     if (stop_after == 2) return;
     // ---- X = L^-1 ----
-    // (1) inverses of the 16x16 diagonal blocks by doubling, 4 -> 8 -> 16: the 4x4 diagonal blocks by forward substitution (three
-    //     dependent steps), then X21 = -X22 (L21 X11) of every pair of neighbours, one thread per entry, all entries of a stage in
-    //     parallel.  (One thread per COLUMN of a 16x16 block, a forward substitution of sixteen dependent steps with dot products
-    //     of growing length, was 1.35 us of the 11.9 us of a tile: a chain of 136 dependent FMAs.)  sX is zero above the diagonal,
-    //     so the sums run over whole rows / columns without conditions.
-    if (tid < TS) {
-        const int o = (tid >> 2) * 4, c = tid & 3;
-        double x[4];
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            double acc = (r == c) ? 1.0 : 0.0;
-#pragma unroll
-            for (int m = 0; m < r; ++m) acc = fma(-sL[(o + r) * LD + o + m], x[m], acc);
-            x[r] = (r >= c) ? acc * s_rs[o + r] : 0.0;
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) sX[(o + r) * LD + o + c] = x[r];
+    // (1) inverses of the 16x16 diagonal blocks by doubling, 4 -> 8 -> 16: X21 = -X22 (L21 X11) of every pair of neighbours, both
+    //     stages on the matrix cores (one thread per entry on the vector ALU - 72 multiply-adds and 136 LDS reads per thread in the
+    //     last stage - was 1.3 us of a tile; a forward substitution per column before that 1.35 us).  sX is zero above the diagonal.
+    // (the 4x4 diagonal blocks of X were written by the sweep's last phase, from the unit factors it had inverted anyway)
+    if (tid < 64 * ((TS / 8 + 3) / 4)) { // 4 -> 8 on the matrix cores: X21 = -X22 (L21 X11) of the TS/8 blocks of eight, four blocks per instruction
+        const int lane = tid & 63, blk = (lane >> 2) & 3, hi = lane >> 4, lo = lane & 3;
+        const int bq = 4 * (tid >> 6) + blk;
+        const bool live = bq < TS / 8;
+        const int o = 8 * (live ? bq : 0);
+        // v_mfma_f64_4x4x4_4b: A[blk][i][k] in lane 16 k + 4 blk + i, B[blk][k][j] in lane 16 k + 4 blk + j, D[blk][i][j] in lane
+        // 16 i + 4 blk + j (tools/mfma_f64_4x4x4_layout.hip) - D of the first product is the B operand of the second as it stands
+        const double a1 = sL[(o + 4 + lo) * LD + o + hi], b1 = sX[(o + hi) * LD + o + lo];
+        const double a2 = sX[(o + 4 + lo) * LD + o + 4 + hi];
+        const double t = __builtin_amdgcn_mfma_f64_4x4x4f64(a1, b1, 0.0, 0, 0, 0);
+        const double r = __builtin_amdgcn_mfma_f64_4x4x4f64(a2, t, 0.0, 0, 0, 0);
+        if (live) sX[(o + 4 + hi) * LD + o + lo] = -r;
     }
     __syncthreads();
-    if (tid < (TS / 8) * 16) { // 4 -> 8: entry (r, c) of X21 in the 8x8 block at o
-        const int o = (tid >> 4) * 8, r = (tid >> 2) & 3, c = tid & 3;
-        double t[4];
+    if (tid < (TS / 16) * 64) { // 8 -> 16, one wave per block of sixteen: rows 8..15 of (L X) over k < 8, then X22 times that
+        const int o = (tid >> 6) * 16, lane = tid & 63, m = lane & 15, kq = lane >> 4;
+        // rows < 8 of both products are not used (their A rows hold L11 / zeros): only rows 8..15, columns 0..7 are stored
+        v4f64 t = {0.0, 0.0, 0.0, 0.0}, r = {0.0, 0.0, 0.0, 0.0};
+        double a[2], bb[2], a2[2];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            double a = 0.0;
-#pragma unroll
-            for (int m = 0; m < 4; ++m) a = fma(sL[(o + 4 + k) * LD + o + m], sX[(o + m) * LD + o + c], a);
-            t[k] = a;
+        for (int q = 0; q < 2; ++q) {
+            a[q] = m >= 8 ? sL[(o + m) * LD + o + 4 * q + kq] : 0.0;
+            bb[q] = sX[(o + 4 * q + kq) * LD + o + m];
+            a2[q] = sX[(o + m) * LD + o + 8 + 4 * q + kq];
         }
-        double v = 0.0;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v = fma(sX[(o + 4 + r) * LD + o + 4 + k], t[k], v);
-        sX[(o + 4 + r) * LD + o + c] = -v;
+        for (int q = 0; q < 2; ++q) t = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], bb[q], t, 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) r = __builtin_amdgcn_mfma_f64_16x16x4f64(a2[q], t[2 + q], r, 0, 0, 0);
+        if (m < 8) {
+#pragma unroll
+            for (int q = 2; q < 4; ++q) sX[(o + kq + 4 * q) * LD + o + m] = -r[q];
+        }
     }
     __syncthreads();
-    if (tid < (TS / 16) * 64) { // 8 -> 16: entry (r, c) of X21 in the 16x16 block at o
-        const int o = (tid >> 6) * 16, r = (tid >> 3) & 7, c = tid & 7;
-        double t[8];
-#pragma unroll
-        for (int k = 0; k < 8; ++k) {
-            double a0 = 0.0, a1 = 0.0;
-#pragma unroll
-            for (int m = 0; m < 8; m += 2) {
-                a0 = fma(sL[(o + 8 + k) * LD + o + m], sX[(o + m) * LD + o + c], a0);
-                a1 = fma(sL[(o + 8 + k) * LD + o + m + 1], sX[(o + m + 1) * LD + o + c], a1);
-            }
-            t[k] = a0 + a1;
-        }
-        double v0 = 0.0, v1 = 0.0;
-#pragma unroll
-        for (int k = 0; k < 8; k += 2) {
-            v0 = fma(sX[(o + 8 + r) * LD + o + 8 + k], t[k], v0);
-            v1 = fma(sX[(o + 8 + r) * LD + o + 8 + k + 1], t[k + 1], v1);
-        }
-        sX[(o + 8 + r) * LD + o + c] = -(v0 + v1);
-    }
-    __syncthreads();
+    TS_MARK(7); // 16x16 diagonal blocks of X
     if (stop_after == 3) return;
     // (2) off-diagonal blocks, one block column per wave: X_ij = -X_ii * sum_{m=j}^{i-1} L_im X_mj
     {
@@ -600,6 +618,7 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
         }
     }
     __syncthreads();
+    TS_MARK(8); // off-diagonal blocks of X
     if (stop_after == 4) return;
     {
         double* X = Linv + (size_t)k * TS * TS;
@@ -609,6 +628,7 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
             if ((TS * TS) % kPotrfThreads == 0 || q < TS * TS) X[q] = sX[(q / TS) * LD + (q % TS)];
         }
     }
+    TS_MARK(9); // X stored
     // y_k = L_kk^-1 g_k (g_k is final: every earlier column has already subtracted its part)
     if (tid < TS) {
         double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0; // X is zero above the diagonal; four partial sums (latency)
@@ -641,6 +661,7 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
             xs[k * TS + tid] = (a0 + a1) + (a2 + a3);
         }
     }
+    TS_MARK(10);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -1145,6 +1166,23 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
         const int i0 = p.h_trsm_ptr[st], ni = p.h_trsm_ptr[st + 1] - i0;
         if (ni > 0 && !Fold<TS>::on) hipLaunchKernelGGL(k_trsm<TS>, dim3(ni * QT * QT), dim3(kBlock), lds_g, s, S, Lt, Linv, p.st_tile + i0, p.st_col + i0, status);
     }
+#ifdef POTRF_TS
+    {
+        static int calls = 0;
+        if (++calls == 100 && TS == 48) {
+            unsigned long long h[64 * 12];
+            int cnt = 0;
+            if (hipStreamSynchronize(s) == hipSuccess && hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ts), sizeof(h)) == hipSuccess &&
+                hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(g_ts_cnt), sizeof(int)) == hipSuccess)
+                for (int st = 0; st < p.n_steps; ++st) {
+                    const int slot = (cnt - p.n_steps + st) & 63;
+                    fprintf(stderr, "TS level %2d:", st);
+                    for (int i = 1; i <= 10; ++i) fprintf(stderr, " %6lld", (long long)(h[slot * 12 + i] - h[slot * 12]));
+                    fprintf(stderr, "\n");
+                }
+        }
+    }
+#endif
     if constexpr (TS == 48) {
         if (one_launch) {
             hipLaunchKernelGGL(k_back_solve_all<TS>, dim3(p.n_solve_cols), dim3(kPotrfThreads), 0, s, p.solve_recs, Lt, Linv, yv, x, status);
