@@ -220,6 +220,10 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
     constexpr int NBLK = NB * (NB + 1) / 2, NWV = kPotrfThreads / 64, PER = (NBLK + NWV - 1) / NWV;
     static_assert(kPotrfThreads == 512, "TileRegs assumes 512 threads");
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, ln = lane & 15, lk = lane >> 4;
+    // g_k and its pending updates live on the LAST wave (no block of the folded products is its): on wave 0 the 48-long dot
+    // products (96 LDS reads per lane) ran behind that wave's own matrix-core block, 0.5 us per level
+    const int gt = tid - (kPotrfThreads - 64 * ((TS + 63) / 64));
+    const bool g_thr = gt >= 0 && gt < TS;
     int ba[PER], bb[PER];
     bool own[PER];
     v4f64 acc[PER];
@@ -289,14 +293,14 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
 #pragma unroll
             for (int u = 0; u < PER; ++u)
                 if (own[u]) accU[u] = mfma_block_acc<TS, LD>(sT, 16 * ba[u], sT, 16 * bb[u], accU[u]);
-            if (tid < TS) {
+            if (g_thr) { // (on the last wave: it owns no block of the product above)
                 double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll 6
                 for (int m = 0; m < TS; m += 4) {
-                    a0 = fma(sT[tid * LD + m], s_rs[m], a0);
-                    a1 = fma(sT[tid * LD + m + 1], s_rs[m + 1], a1);
-                    a2 = fma(sT[tid * LD + m + 2], s_rs[m + 2], a2);
-                    a3 = fma(sT[tid * LD + m + 3], s_rs[m + 3], a3);
+                    a0 = fma(sT[gt * LD + m], s_rs[m], a0);
+                    a1 = fma(sT[gt * LD + m + 1], s_rs[m + 1], a1);
+                    a2 = fma(sT[gt * LD + m + 2], s_rs[m + 2], a2);
+                    a3 = fma(sT[gt * LD + m + 3], s_rs[m + 3], a3);
                 }
                 gk -= (a0 + a1) + (a2 + a3);
             }
@@ -317,21 +321,21 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
 #pragma unroll
         for (int u = 0; u < PER; ++u)
             if (own[u]) accU[u] = mfma_block_acc<TS, LD>(sL, 16 * ba[u], sL, 16 * bb[u], accU[u]);
-        if (tid < TS) { // four partial sums: a single chain of TS dependent FP64 FMAs (36 cycles each) would cost 1.4 us
+        if (g_thr) { // four partial sums: a single chain of TS dependent FP64 FMAs (36 cycles each) would cost 1.4 us
             double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll 6
             for (int m = 0; m < TS; m += 4) {
-                a0 = fma(sL[tid * LD + m], s_rs[m], a0);
-                a1 = fma(sL[tid * LD + m + 1], s_rs[m + 1], a1);
-                a2 = fma(sL[tid * LD + m + 2], s_rs[m + 2], a2);
-                a3 = fma(sL[tid * LD + m + 3], s_rs[m + 3], a3);
+                a0 = fma(sL[gt * LD + m], s_rs[m], a0);
+                a1 = fma(sL[gt * LD + m + 1], s_rs[m + 1], a1);
+                a2 = fma(sL[gt * LD + m + 2], s_rs[m + 2], a2);
+                a3 = fma(sL[gt * LD + m + 3], s_rs[m + 3], a3);
             }
             gk -= (a0 + a1) + (a2 + a3);
         }
         __syncthreads();
     }
     }
-    if (tid < TS) s_g[tid] = gk; // g_k minus the pending sources: read again when y_k is formed, many barriers from here
+    if (g_thr) s_g[gt] = gk; // g_k minus the pending sources: read again when y_k is formed, many barriers from here
 #pragma unroll
     for (int u = 0; u < PER; ++u)
 #pragma unroll
@@ -407,7 +411,7 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
                 }
             // the pivots go out LAST: a store inside the chain (or in front of the panel reads) would put its LDS round
             // trip, through the in-order wait for the next reads, on the dependent path
-            if (tid == 0) {
+            if (tid == kPotrfThreads - 64) { // (a wave without blocks: on wave 0 these stores delayed its next quad, 50 cycles each)
 #pragma unroll
                 for (int m = 0; m < KB; ++m) s_rs[j + m] = w[m][m];
                 // the inverse of the quad's unit factor is the 4x4 diagonal block of L^-1 up to the row scaling: kept for the
@@ -535,7 +539,10 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
     // g_k is requested here and parked in LDS by the sweep once the operand tiles are on their way (a store to LDS right here
     // would wait for this load alone: one memory round trip in front of all the others)
     double gk = 0.0;
-    if (tid < TS) gk = g[k * TS + tid];
+    {
+        const int gt = tid - (kPotrfThreads - 64 * ((TS + 63) / 64)); // (the sweep keeps g_k on the last wave(s))
+        if (gt >= 0 && gt < TS) gk = g[k * TS + gt];
+    }
     const int rc = potrf_sweep_mfma<TS>(A, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y, Lt, sa.pre_tile + pre0, sa.pre_col + pre0, npre, s_g, S,
                                         Linv, sm + 2 * TS * LD, status, it0, it1, ic0, ic1, gk, s_cf);
     if (rc == 2) return;                                  // an earlier column of this trial had failed
