@@ -592,35 +592,69 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
     __syncthreads();
     TS_MARK(7); // 16x16 diagonal blocks of X
     if (stop_after == 3) return;
-    // (2) off-diagonal blocks, one block column per wave: X_ij = -X_ii * sum_{m=j}^{i-1} L_im X_mj
-    {
+    // (2) off-diagonal blocks: X_ij = -X_ii * sum_{m=j}^{i-1} L_im X_mj
+    if constexpr (NB == 3) {
+        // three blocks.  X_10 and X_21 on waves 0 and 1, and wave 2 starts X_20 with the product that needs neither (L_20 X_00);
+        // after a barrier it adds L_21 X_10 and multiplies by X_22 - a chain of eight dependent matrix-core steps on either side
+        // of the barrier, where one wave walking block column 0 made twenty.
         const int wave = tid >> 6, lane = tid & 63;
-        for (int j = wave; j < NB - 1; j += kPotrfThreads / 64) {
-            for (int i = j + 1; i < NB; ++i) {
-                // X_ii operand first: it depends on nothing of this step
-                const double* pd = sX + (16 * i + (lane & 15)) * LD + 16 * i + (lane >> 4);
-                double dv[4];
+        auto lx = [&](int i, int m, int j, v4f64 acc) { // acc += L_im X_mj
+            const double* pa = sL + (16 * i + (lane & 15)) * LD + 16 * m + (lane >> 4);
+            const double* pb = sX + (16 * m + (lane >> 4)) * LD + 16 * j + (lane & 15);
+            double av[4], bv[4];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) dv[q] = pd[4 * q];
-                v4f64 acc = {0.0, 0.0, 0.0, 0.0};
-                for (int m = j; m < i; ++m) {
-                    const double* pa = sL + (16 * i + (lane & 15)) * LD + 16 * m + (lane >> 4);
-                    const double* pb = sX + (16 * m + (lane >> 4)) * LD + 16 * j + (lane & 15);
-                    double av[4], bv[4];
+            for (int q = 0; q < 4; ++q) { av[q] = pa[4 * q]; bv[q] = pb[4 * q * LD]; }
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) { av[q] = pa[4 * q]; bv[q] = pb[4 * q * LD]; }
+            for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+            return acc;
+        };
+        auto finish = [&](int i, int j, const v4f64& acc) { // X_ij = -X_ii acc: the accumulator layout IS the B-operand layout
+            const double* pd = sX + (16 * i + (lane & 15)) * LD + 16 * i + (lane >> 4);
+            double dv[4];
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+            for (int q = 0; q < 4; ++q) dv[q] = pd[4 * q];
+            v4f64 r = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; ++q) r = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[q], acc[q], r, 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sX[(16 * i + (lane >> 4) + 4 * q) * LD + 16 * j + (lane & 15)] = -r[q];
+        };
+        v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+        if (wave == 0) { acc = lx(1, 0, 0, acc); finish(1, 0, acc); }
+        else if (wave == 1) { acc = lx(2, 1, 1, acc); finish(2, 1, acc); }
+        else if (wave == 2) acc = lx(2, 0, 0, acc);
+        __syncthreads();
+        if (wave == 2) { acc = lx(2, 1, 0, acc); finish(2, 0, acc); }
+    } else {
+        {
+            const int wave = tid >> 6, lane = tid & 63;
+            for (int j = wave; j < NB - 1; j += kPotrfThreads / 64) {
+                for (int i = j + 1; i < NB; ++i) {
+                    // X_ii operand first: it depends on nothing of this step
+                    const double* pd = sX + (16 * i + (lane & 15)) * LD + 16 * i + (lane >> 4);
+                    double dv[4];
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) dv[q] = pd[4 * q];
+                    v4f64 acc = {0.0, 0.0, 0.0, 0.0};
+                    for (int m = j; m < i; ++m) {
+                        const double* pa = sL + (16 * i + (lane & 15)) * LD + 16 * m + (lane >> 4);
+                        const double* pb = sX + (16 * m + (lane >> 4)) * LD + 16 * j + (lane & 15);
+                        double av[4], bv[4];
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q) { av[q] = pa[4 * q]; bv[q] = pb[4 * q * LD]; }
+    #pragma unroll
+                        for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av[q], bv[q], acc, 0, 0, 0);
+                    }
+                    // the accumulator layout (row (lane>>4) + 4q, column lane&15) IS the B-operand layout of the next product
+                    // (k = (lane>>4) + 4q, n = lane&15): no trip through LDS
+                    v4f64 r = {0.0, 0.0, 0.0, 0.0};
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) r = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[q], acc[q], r, 0, 0, 0);
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) sX[(16 * i + (lane >> 4) + 4 * q) * LD + 16 * j + (lane & 15)] = -r[q];
+                    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+                    __builtin_amdgcn_wave_barrier();
                 }
-                // the accumulator layout (row (lane>>4) + 4q, column lane&15) IS the B-operand layout of the next product
-                // (k = (lane>>4) + 4q, n = lane&15): no trip through LDS
-                v4f64 r = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-                for (int q = 0; q < 4; ++q) r = __builtin_amdgcn_mfma_f64_16x16x4f64(dv[q], acc[q], r, 0, 0, 0);
-#pragma unroll
-                for (int q = 0; q < 4; ++q) sX[(16 * i + (lane >> 4) + 4 * q) * LD + 16 * j + (lane & 15)] = -r[q];
-                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-                __builtin_amdgcn_wave_barrier();
             }
         }
     }
@@ -636,17 +670,27 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
         }
     }
     TS_MARK(9); // X stored
-    // y_k = L_kk^-1 g_k (g_k is final: every earlier column has already subtracted its part)
-    if (tid < TS) {
-        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0; // X is zero above the diagonal; four partial sums (latency)
-#pragma unroll 6
-        for (int c = 0; c < TS; c += 4) {
-            a0 = fma(sX[tid * LD + c], s_g[c], a0);
-            a1 = fma(sX[tid * LD + c + 1], s_g[c + 1], a1);
-            a2 = fma(sX[tid * LD + c + 2], s_g[c + 2], a2);
-            a3 = fma(sX[tid * LD + c + 3], s_g[c + 3], a3);
+    // y_k = L_kk^-1 g_k (g_k is final: every earlier column has already subtracted its part).  Four threads per row, a quarter of
+    // the columns each, the partial sums added in a fixed order: one thread per row was a chain of TS LDS reads and multiply-adds
+    // (0.65 us) at the very end of the level.
+    constexpr int YP = 4, YC = TS / YP;
+    static_assert(YP * TS <= kPotrfThreads && YP * TS <= kScratch && YC % 4 == 0, "y_k partial sums");
+    double* s_yp = s_buf; // [YP][TS]: the sweep's column scratch is free by now
+    if (tid < YP * TS) {
+        const int part = tid / TS, r = tid - part * TS;
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0; // X is zero above the diagonal
+#pragma unroll
+        for (int c = part * YC; c < part * YC + YC; c += 4) {
+            a0 = fma(sX[r * LD + c], s_g[c], a0);
+            a1 = fma(sX[r * LD + c + 1], s_g[c + 1], a1);
+            a2 = fma(sX[r * LD + c + 2], s_g[c + 2], a2);
+            a3 = fma(sX[r * LD + c + 3], s_g[c + 3], a3);
         }
-        const double yk = (a0 + a1) + (a2 + a3);
+        s_yp[part * TS + r] = (a0 + a1) + (a2 + a3);
+    }
+    __syncthreads();
+    if (tid < TS) {
+        const double yk = (s_yp[tid] + s_yp[TS + tid]) + (s_yp[2 * TS + tid] + s_yp[3 * TS + tid]);
         if (!sa.last_level) {
             y[k * TS + tid] = yk;
             if (xs != y) xs[k * TS + tid] = solve_pending(); // the one-launch backward substitution waits on this value
