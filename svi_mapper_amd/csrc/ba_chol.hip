@@ -104,6 +104,9 @@ __device__ __forceinline__ v4f64 mfma_block(const double* sA, int ra, const doub
     double a[KK / 4], b[KK / 4];
 #pragma unroll
     for (int q = 0; q < KK / 4; ++q) { a[q] = pa[4 * q]; b[q] = pb[4 * q]; }
+    // every operand read is issued before the first product: left to itself the scheduler recycles two operand registers and
+    // puts an LDS round trip between every pair of matrix-core steps (2300 cycles for twelve steps instead of 900, in the ISA)
+    __builtin_amdgcn_sched_barrier(0);
     v4f64 acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
     for (int q = 0; q < KK / 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
@@ -116,8 +119,17 @@ __device__ __forceinline__ v4f64 mfma_block_acc(const double* sA, int ra, const 
     const int lane = threadIdx.x & 63;
     const double* pa = sA + (ra + (lane & 15)) * LD + (lane >> 4);
     const double* pb = sB + (rb + (lane & 15)) * LD + (lane >> 4);
+    if constexpr (KK <= 48) {
+        double a[KK / 4], b[KK / 4];
+#pragma unroll
+        for (int q = 0; q < KK / 4; ++q) { a[q] = pa[4 * q]; b[q] = pb[4 * q]; }
+        __builtin_amdgcn_sched_barrier(0); // (as above: all reads first)
+#pragma unroll
+        for (int q = 0; q < KK / 4; ++q) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a[q], b[q], acc, 0, 0, 0);
+    } else {
 #pragma unroll 6
-    for (int k0 = 0; k0 < KK; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0], acc, 0, 0, 0);
+        for (int k0 = 0; k0 < KK; k0 += 4) acc = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[k0], pb[k0], acc, 0, 0, 0);
+    }
     return acc;
 }
 
@@ -284,6 +296,7 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
                     if (st < 0) continue;
                     const int r0 = (st / NB) * 16, c0 = (st % NB) * 16;
                     const v4f64 lb = mfma_block_tri<TS, LD>(sX, r0, sL, c0);
+                    if (u == 0) TS_MARK(11);
                     block_to_lds<LD>(lb, sT, r0, c0);
                     block_to_global<TS>(lb, Lout, r0, c0);
                 }
@@ -1228,7 +1241,7 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
                 for (int st = 0; st < p.n_steps; ++st) {
                     const int slot = (cnt - p.n_steps + st) & 63;
                     fprintf(stderr, "TS level %2d:", st);
-                    for (int i = 1; i <= 10; ++i) fprintf(stderr, " %6lld", (long long)(h[slot * 12 + i] - h[slot * 12]));
+                    for (int i = 1; i <= 11; ++i) fprintf(stderr, " %6lld", (long long)(h[slot * 12 + i] - h[slot * 12]));
                     fprintf(stderr, "\n");
                 }
         }
