@@ -33,9 +33,9 @@ typedef double v4f64 __attribute__((ext_vector_type(4)));
 // -DPOTRF_TS: shader-clock stamps of the first chain workgroup of every level (phase boundaries of k_potrf_inv), printed by
 // run() at its 100th call - how the per-phase figures in DESIGN.md were measured.  Compiled out otherwise.
 #ifdef POTRF_TS
-__device__ unsigned long long g_ts[64 * 12];
+__device__ unsigned long long g_ts[64 * 16];
 __device__ int g_ts_cnt, g_ts_cur;
-#define TS_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_ts[g_ts_cur * 12 + (i)] = clock64(); } while (0)
+#define TS_MARK(i) do { if (threadIdx.x == 0 && blockIdx.x == 0) g_ts[g_ts_cur * 16 + (i)] = clock64(); } while (0)
 #else
 #define TS_MARK(i) do { } while (0)
 #endif
@@ -378,7 +378,9 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
 #pragma unroll
                     for (int q = 0; q < 4; ++q) col[16 * ba[u] + lk + 4 * q][ln & 3] = acc[u][q];
                 }
+            if (jb == 1 && jq == 1) TS_MARK(12); // (one quad in the middle of the sweep: published)
             __syncthreads();
+            if (jb == 1 && jq == 1) TS_MARK(13); // past the barrier
             // KB x KB pivot block, LDL' in registers (every lane redundantly)
             double w[KB][KB], l[KB][KB], rinv[KB];
 #pragma unroll
@@ -399,6 +401,7 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
             // Panel entries by the INVERSE of the unit-triangular pivot factor: the eliminated entry of pivot lk at a row
             // is then one short dot product of the four published values with this lane's coefficient row (no chain of
             // dependent FP64 operations and no per-solve selects), the 1/d scaling of the row operand folded in.
+            if (jb == 1 && jq == 1) TS_MARK(14); // pivot chain done
             const double c10 = -l[1][0], c21 = -l[2][1], c32 = -l[3][2];
             const double c20 = fma(-l[2][1], c10, -l[2][0]), c31 = fma(-l[3][2], c21, -l[3][1]);
             const double c30 = fma(-l[3][2], c20, fma(-l[3][1], c10, -l[3][0]));
@@ -424,6 +427,7 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
                 }
             // the pivots go out LAST: a store inside the chain (or in front of the panel reads) would put its LDS round
             // trip, through the in-order wait for the next reads, on the dependent path
+            if (jb == 1 && jq == 1) TS_MARK(15); // panel + matrix-core step issued
             if (tid == kPotrfThreads - 64) { // (a wave without blocks: on wave 0 these stores delayed its next quad, 50 cycles each)
 #pragma unroll
                 for (int m = 0; m < KB; ++m) s_rs[j + m] = w[m][m];
@@ -1234,14 +1238,14 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
     {
         static int calls = 0;
         if (++calls == 100 && TS == 48) {
-            unsigned long long h[64 * 12];
+            unsigned long long h[64 * 16];
             int cnt = 0;
             if (hipStreamSynchronize(s) == hipSuccess && hipMemcpyFromSymbol(h, HIP_SYMBOL(g_ts), sizeof(h)) == hipSuccess &&
                 hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(g_ts_cnt), sizeof(int)) == hipSuccess)
                 for (int st = 0; st < p.n_steps; ++st) {
                     const int slot = (cnt - p.n_steps + st) & 63;
                     fprintf(stderr, "TS level %2d:", st);
-                    for (int i = 1; i <= 11; ++i) fprintf(stderr, " %6lld", (long long)(h[slot * 12 + i] - h[slot * 12]));
+                    for (int i = 1; i <= 15; ++i) fprintf(stderr, " %6lld", (long long)(h[slot * 16 + i] - h[slot * 16]));
                     fprintf(stderr, "\n");
                 }
         }
