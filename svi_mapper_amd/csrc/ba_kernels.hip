@@ -660,8 +660,6 @@ __device__ __forceinline__ void pose_finalize_block(const BaDev& d, const int* _
     if (idx >= d.Pf * 27) return;
     const int r = idx / 27, v = idx % 27;
     const int s = red_slot[r];
-    double sum = 0.0;
-    for (int c = d.pose_chunk_ptr[s]; c < d.pose_chunk_ptr[s + 1]; ++c) sum += d.chunk_out[(size_t)27 * c + v];
     // position of upper-triangle entry v in a full 6x6
     int rr = 0, cc = 0;
     if (v < 21) {
@@ -670,14 +668,35 @@ __device__ __forceinline__ void pose_finalize_block(const BaDev& d, const int* _
         while (k >= 6 - rr) { k -= 6 - rr; ++rr; }
         cc = rr + k;
     }
-    for (int q = d.pose_aux_ptr[s]; q < d.pose_aux_ptr[s + 1]; ++q) {
-        const int ref = d.pose_aux_ref[q], k = ref >> 2, role = ref & 3;
-        if (role == 2) sum += (v < 21) ? d.acc_out[(size_t)42 * k + 6 * rr + cc] : d.acc_out[(size_t)42 * k + 36 + (v - 21)];
-        else {
-            const double* o = d.se3_out + (size_t)120 * k;
-            sum += (v < 21) ? o[36 * role + 6 * rr + cc] : o[108 + 6 * role + (v - 21)];
-        }
-    }
+    // Dependent round trips are what this launch costs: the four list bounds travel together, then the first two chunk sums
+    // and the first three pose-only edge references (a pose of a trajectory has a chunk or two, two odometry edges and a
+    // gravity edge), then those edges' values - four trips where the plain loops made seven.  Sums in list order as before.
+    const int c0 = d.pose_chunk_ptr[s], c1 = d.pose_chunk_ptr[s + 1], q0 = d.pose_aux_ptr[s], q1 = d.pose_aux_ptr[s + 1];
+    constexpr int PC = 2, PA = 3;
+    double cv[PC];
+    int ref[PA];
+#pragma unroll
+    for (int i = 0; i < PC; ++i) cv[i] = d.chunk_out[(size_t)27 * (c0 + i < c1 ? c0 + i : c0) + v];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) ref[i] = d.pose_aux_ref[q0 + i < q1 ? q0 + i : q0];
+    auto aux_ptr = [&](int rf) -> const double* { // (selects, no branches: the loads below must not sit in divergent regions)
+        const int k = rf >> 2, role = rf & 3;
+        const size_t oa = (size_t)42 * k + ((v < 21) ? 6 * rr + cc : 36 + (v - 21));
+        const size_t os = (size_t)120 * k + ((v < 21) ? 36 * role + 6 * rr + cc : 108 + 6 * role + (v - 21));
+        const double* pa = d.acc_out + oa;
+        const double* ps = d.se3_out + os;
+        return role == 2 ? pa : ps;
+    };
+    double av[PA];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) { const double* pp = aux_ptr(ref[i]); av[i] = *((q0 + i < q1) ? pp : d.scal); }
+    double sum = 0.0;
+#pragma unroll
+    for (int i = 0; i < PC; ++i) if (c0 + i < c1) sum += cv[i];
+    for (int c = c0 + PC; c < c1; ++c) sum += d.chunk_out[(size_t)27 * c + v];
+#pragma unroll
+    for (int i = 0; i < PA; ++i) if (q0 + i < q1) sum += av[i];
+    for (int q = q0 + PA; q < q1; ++q) sum += *aux_ptr(d.pose_aux_ref[q]);
     if (v < 21) d.Hpp[(size_t)21 * r + v] = sum;
     else d.bp[(size_t)6 * r + (v - 21)] = sum;
 }
@@ -1137,15 +1156,31 @@ __global__ __launch_bounds__(kRedThreads) void k_update_poses(BaDev d, int cur, 
     double* __restrict__ dst = d.pose[cur ^ 1];
     double part[1] = {0.0};
     for (int s = threadIdx.x; s < d.Pn; s += kRedThreads) {
+        // the pose travels with its index (six 16-byte loads, nothing waits on them yet): a fixed pose used to be copied word
+        // by word, twelve dependent round trips in ONE lane (the ISA showed load - wait - store twelve times) - which was
+        // this kernel's critical path; a free pose fetched its operands only after the index had arrived
+        double T[12], Tn[12];
+        {
+            const double2* sp = reinterpret_cast<const double2*>(src + 12 * s);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { const double2 v = sp[k]; T[2 * k] = v.x; T[2 * k + 1] = v.y; }
+        }
         const int r = d.pose_red[s];
         if (r < 0) {
-            for (int k = 0; k < 12; ++k) dst[12 * s + k] = src[12 * s + k];
+#pragma unroll
+            for (int k = 0; k < 12; ++k) Tn[k] = T[k];
         } else {
-            double dl[6];
+            double dl[6], bl[6];
             const double wl = (scale_mode == 0 || rank == 0) ? lambda : 0.0, wb = (scale_mode == 1 && rank != 0) ? 0.0 : 1.0;
-            for (int k = 0; k < 6; ++k) { dl[k] = d.dx[6 * r + k]; part[0] += dl[k] * (wl * dl[k] + wb * d.bp[6 * r + k]); }
-            pose_oplus(src + 12 * s, dl, dst + 12 * s);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { dl[k] = d.dx[6 * r + k]; bl[k] = d.bp[6 * r + k]; }
+#pragma unroll
+            for (int k = 0; k < 6; ++k) part[0] += dl[k] * (wl * dl[k] + wb * bl[k]);
+            pose_oplus(T, dl, Tn);
         }
+        double2* dp = reinterpret_cast<double2*>(dst + 12 * s);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dp[k] = make_double2(Tn[2 * k], Tn[2 * k + 1]);
     }
     block_sum<1, NW>(part, s_red);
     if (threadIdx.x == 0) {

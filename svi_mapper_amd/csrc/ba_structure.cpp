@@ -481,6 +481,7 @@ int aux_edges(Build& b)
         b.pose_aux_ref.insert(b.pose_aux_ref.end(), pose_aux[s].begin(), pose_aux[s].end());
     }
     b.pose_aux_ptr[Pn] = (int)b.pose_aux_ref.size();
+    b.pose_aux_ref.insert(b.pose_aux_ref.end(), 4, 0); // (pose_finalize_block reads three references ahead of a list's start)
     struct LL { int free_l; double ref[3], z[3], info[6]; uint8_t robust; };
     std::vector<LL> v;
     for (const HLL& e : ba->lmlm) {
@@ -949,7 +950,7 @@ int upload(Build& b)
     SVI_TRY(up.alloc((size_t)3 * Ll, &d.bl));
     SVI_TRY(up.alloc((size_t)6 * Ll, &d.Hinv));
     SVI_TRY(up.alloc((size_t)12 * std::max(Ll, 1), &d.HinvB));
-    SVI_TRY(up.alloc((size_t)27 * b.n_chunks, &d.chunk_out));
+    SVI_TRY(up.alloc((size_t)27 * (b.n_chunks + 2), &d.chunk_out)); // (+2: pose_finalize_block requests two chunks unconditionally)
     SVI_TRY(up.alloc((size_t)120 * d.n_se3, &d.se3_out));
     SVI_TRY(up.alloc((size_t)42 * d.n_accel, &d.acc_out));
     d.lin_count = 27 * Pf + 2 + o.n_ranks;
