@@ -853,7 +853,12 @@ __device__ __forceinline__ void schur_fetch(const BaDev& d, const int4 (&pk)[kSc
         const unsigned e = on ? (unsigned)((row ? pk[t].y : pk[t].z - 4) + es) : 0u;
 #pragma unroll
         for (int q = 0; q < 3; ++q) { // the lane's six values are three double2 planes
+#if SCHUR_ABL == 3 || SCHUR_ABL == 4
+            // (ablation: the same bytes addressed as 96-byte records per edge - what an array-of-records layout would cost to stage)
+            const double2 x = *reinterpret_cast<const double2*>(nzp + (size_t)e * 12 + 6 * pg + 2 * q);
+#else
             const double2 x = ldp2(nzp, E, 3 * pg + q, e);
+#endif
             st.v[t][2 * q] = x.x; st.v[t][2 * q + 1] = x.y;
         }
         st.hv[t] = d.HinvB[(size_t)12 * (unsigned)pk[t].x + (l16 < 9 ? l16 : 0)];
@@ -923,7 +928,7 @@ __global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
             const bool active = ((mI >> i) & 1u) && ((mJ >> j) & 1u) && (!diag || i >= j);
             if (!active) continue;
             const double* slot = s_stage[wave][buf][t][qt];
-#if SCHUR_ABL == 1
+#if SCHUR_ABL == 1 || SCHUR_ABL == 3
             acc[0] += slot[12 * __popc(mI & below_i)] + slot[96]; continue;
 #endif
             const double* na = slot + 12 * __popc(mI & below_i);
