@@ -49,6 +49,7 @@ struct BaDev {
     const double*  e_zi;    // [(3 + info_planes + 1) / 2][E] double2: z (3), information (info_planes), pad
     const int*     lm_ptr;  // [Ll+1] edges of landmark l
     const int*     lb_lm;   // [n_lm_blocks+1] landmarks of lm-major workgroup b
+    const int*     lb_rec;  // [n_lm_blocks][4] {first landmark, #landmarks, first edge, end edge} of workgroup b (one load)
     // pose-major copy
     const int*     pm_lm;    // [E]
     const uint8_t* pm_flags; // [E]

@@ -213,10 +213,8 @@ template <bool DIAG>
 __device__ __forceinline__ void lm_fetch(const BaDev& d, int b, LmFetch<DIAG>& f)
 {
     const int tid = threadIdx.x;
-    f.l0 = d.lb_lm[b];
-    const int l1 = d.lb_lm[b + 1];
-    f.nl = l1 - f.l0;
-    f.e0 = d.lm_ptr[f.l0]; f.e1 = d.lm_ptr[l1];
+    const int4 rec = reinterpret_cast<const int4*>(d.lb_rec)[b];
+    f.l0 = rec.x; f.nl = rec.y; f.e0 = rec.z; f.e1 = rec.w;
     const int e = min(f.e0 + tid, f.e1 - 1);
     load_edge<DIAG>(d.e_zi, d.e_flags, d.E, e, f.in);
     f.s = d.e_pose[e]; f.l = d.e_lm[e];
@@ -1206,8 +1204,8 @@ __global__ __launch_bounds__(kBlock) void k_backsub_chi2(BaDev d, int cur, doubl
     __shared__ double s_v[3][kLmBlockEdges];
     __shared__ double s_lm[3][kLmBlockEdges];
     const int b = blockIdx.x, tid = threadIdx.x;
-    const int l0 = d.lb_lm[b], l1 = d.lb_lm[b + 1];
-    const int e0 = d.lm_ptr[l0], e1 = d.lm_ptr[l1];
+    const int4 rec = reinterpret_cast<const int4*>(d.lb_rec)[b];
+    const int l0 = rec.x, l1 = rec.x + rec.y, e0 = rec.z, e1 = rec.w;
     const size_t E = d.E, Ll = d.Ll;
     const int e = e0 + tid;
     const int trial = BACKSUB ? (cur ^ 1) : cur;

@@ -84,7 +84,7 @@ struct Build {
     int span = 0;
     // this rank
     int L0 = 0, Ll = 0, E = 0, Epm = 0;
-    std::vector<int> loc, e_pose, e_lm, lm_ptr, lb_lm, pm, pm_src, chunk_pose, chunk_begin, pose_chunk_ptr;
+    std::vector<int> loc, e_pose, e_lm, lm_ptr, lb_lm, lb_rec, pm, pm_src, chunk_pose, chunk_begin, pose_chunk_ptr;
     std::vector<uint8_t> lm_fixed;
     int n_lm_blocks = 0, n_chunks = 0, planes = 3;
     // aux
@@ -108,7 +108,7 @@ struct Build {
     {
         pose_slot.clear(); pose_red.clear(); red_slot.clear(); lm_slot.clear(); g_edge.clear(); g_pose.clear(); g_ptr.clear();
         tmp_ls.clear(); tmp_ps.clear(); tmp_cur.clear(); cpl.clear(); cpl_lo.clear(); loc.clear(); e_pose.clear();
-        e_lm.clear(); lm_ptr.clear(); lb_lm.clear(); pm.clear(); pm_src.clear(); chunk_pose.clear(); chunk_begin.clear();
+        e_lm.clear(); lm_ptr.clear(); lb_lm.clear(); lb_rec.clear(); pm.clear(); pm_src.clear(); chunk_pose.clear(); chunk_begin.clear();
         pose_chunk_ptr.clear(); lm_fixed.clear(); se3_i.clear(); se3_j.clear(); acc_pose.clear(); ll_free.clear();
         lm_ll_ptr.clear(); pose_aux_ptr.clear(); pose_aux_ref.clear(); se3_Z.clear(); se3_info.clear(); acc_a.clear();
         acc_info.clear(); ll_ref.clear(); ll_z.clear(); ll_info.clear(); se3_robust.clear(); ll_robust.clear();
@@ -426,6 +426,13 @@ int local_edges(Build& b)
         l = l2;
     }
     b.n_lm_blocks = (int)b.lb_lm.size() - 1;
+    // one 16-byte record per workgroup {first landmark, #landmarks, first edge, end edge}: lb_lm -> lm_ptr was two dependent
+    // round trips at the head of every landmark-major workgroup
+    b.lb_rec.resize((size_t)4 * std::max(b.n_lm_blocks, 1), 0);
+    for (int k = 0; k < b.n_lm_blocks; ++k) {
+        const int l0 = b.lb_lm[k], l1 = b.lb_lm[k + 1];
+        b.lb_rec[4 * k] = l0; b.lb_rec[4 * k + 1] = l1 - l0; b.lb_rec[4 * k + 2] = b.lm_ptr[l0]; b.lb_rec[4 * k + 3] = b.lm_ptr[l1];
+    }
     b.lm_fixed.resize(Ll);
     for (int l = 0; l < Ll; ++l) b.lm_fixed[l] = (uint8_t)(ba->lms[ba->lm_order[b.L0 + l]].fixed ? 1 : 0);
     // pose-major copy: free poses only, (pose slot, lm-major position): a stable counting sort
@@ -903,6 +910,7 @@ int upload(Build& b)
     SVI_TRY(up.up(b.e_lm, &d.e_lm));
     SVI_TRY(up.up(b.lm_ptr, &d.lm_ptr));
     SVI_TRY(up.up(b.lb_lm, &d.lb_lm));
+    SVI_TRY(up.up(b.lb_rec, &d.lb_rec));
     {
         const int* p = nullptr;
         SVI_TRY(up.up(b.red_slot, &p)); ba->red_slot = const_cast<int*>(p);
