@@ -22,6 +22,7 @@
 #include <vector>
 
 #include "ba_device.h"
+#include "ba_math.h"
 
 namespace svi {
 namespace {
@@ -1106,11 +1107,72 @@ __global__ __launch_bounds__(kPotrfThreads) void k_back_solve_inl(SolveInline si
 // waits, entry by entry, for the x_i of the rows above: the forward phase left "pending" markers in the solution vector, a
 // marker that disappears IS the hand-over (one remote read per dependency level: 16 hops instead of 16 launches).  Every wait
 // is bounded: a value that never arrives (which would be a defect) ends the kernel with a status instead of hanging the GPU.
+// The trial poses, by one extra workgroup of k_back_solve_all: a lane per pose, waiting for that pose's six dx entries the way
+// the column workgroups wait for their x segments (bounded; a timeout or a failed factorisation ends the trial as failed).
+__device__ void pose_tail_wg(const PoseTail& pt, const double* x, int* status)
+{
+    constexpr int NW = kPotrfThreads / 64, kSpinLimit = 1 << 22;
+    __shared__ double s_red[NW];
+    __shared__ int s_bad;
+    if (threadIdx.x == 0) s_bad = 0;
+    __syncthreads();
+    double part = 0.0;
+    for (int s = threadIdx.x; s < pt.Pn; s += kPotrfThreads) {
+        double T[12], Tn[12];
+        {
+            const double2* sp = reinterpret_cast<const double2*>(pt.src + 12 * s);
+#pragma unroll
+            for (int k = 0; k < 6; ++k) { const double2 v = sp[k]; T[2 * k] = v.x; T[2 * k + 1] = v.y; }
+        }
+        const int r = pt.pose_red[s];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) Tn[k] = T[k];
+        if (r >= 0) {
+            double dl[6], bl[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k) bl[k] = pt.bp[6 * r + k];
+            bool pending = true;
+            for (int spins = 0; pending; ++spins) {
+                pending = false;
+#pragma unroll
+                for (int k = 0; k < 6; ++k) { dl[k] = __hip_atomic_load(x + 6 * r + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); pending = pending || is_solve_pending(dl[k]); }
+                if (pending && (spins >= kSpinLimit || ((spins & 255) == 255 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0))) break;
+            }
+            if (pending) s_bad = 1; // (the pose stays where it is)
+            else {
+#pragma unroll
+                for (int k = 0; k < 6; ++k) part += dl[k] * (pt.wl * dl[k] + pt.wb * bl[k]);
+                pose_oplus(T, dl, Tn);
+            }
+        }
+        double2* dp = reinterpret_cast<double2*>(pt.dst + 12 * s);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dp[k] = make_double2(Tn[2 * k], Tn[2 * k + 1]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) part += __shfl_xor(part, off);
+    if ((threadIdx.x & 63) == 0) s_red[threadIdx.x >> 6] = part;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double sum = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) sum += s_red[w];
+        pt.scal[3] = sum;
+        if (pt.lin_from_red) { pt.scal[8] = pt.red_base[0]; pt.scal[9] = pt.red_base[1]; }
+        if (s_bad) atomicCAS(status, 0, -3);
+    }
+}
+
 template <int TS>
 __global__ __launch_bounds__(kPotrfThreads) void k_back_solve_all(const SolveRec* __restrict__ recs, const double* __restrict__ Lt,
-                                                                  const double* __restrict__ Linv, const double* __restrict__ y, double* x, int* status)
+                                                                  const double* __restrict__ Linv, const double* __restrict__ y, double* x, int* status,
+                                                                  PoseTail pt)
 {
     static_assert(TS == 48, "written for the 48-wide tile (one column set per lane)");
+    if (pt.src != nullptr && blockIdx.x == gridDim.x - 1) { // the extra workgroup: the trial poses
+        if (*status == 0) pose_tail_wg(pt, x, status);
+        return;
+    }
     constexpr int NW = kPotrfThreads / 64, RB = 24, NRB = TS / RB, MAXU = (kInlineSub * NRB + NW - 1) / NW;
     constexpr int kSpinLimit = 1 << 22;
     __shared__ double s_part[NW][TS];
@@ -1202,8 +1264,10 @@ __global__ __launch_bounds__(kPotrfThreads) void k_back_solve_all(const SolveRec
 }
 
 template <int TS>
-int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n, int* status, hipStream_t s)
+int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n, int* status, hipStream_t s,
+        const PoseTail* tail, int* tail_done)
 {
+    if (tail_done) *tail_done = 0;
     // one-launch backward substitution (tile 48, every column's list short enough): the forward vector then lives in p.ybuf and
     // the solution vector carries "pending" markers until its entries are computed
     const bool one_launch = TS == 48 && p.solve_recs != nullptr && p.n_solve_cols > 0 && p.ybuf != nullptr;
@@ -1253,7 +1317,9 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
 #endif
     if constexpr (TS == 48) {
         if (one_launch) {
-            hipLaunchKernelGGL(k_back_solve_all<TS>, dim3(p.n_solve_cols), dim3(kPotrfThreads), 0, s, p.solve_recs, Lt, Linv, yv, x, status);
+            PoseTail pt{};
+            if (tail) { pt = *tail; if (tail_done) *tail_done = 1; }
+            hipLaunchKernelGGL(k_back_solve_all<TS>, dim3(p.n_solve_cols + (tail ? 1 : 0)), dim3(kPotrfThreads), 0, s, p.solve_recs, Lt, Linv, yv, x, status, pt);
             return 0;
         }
     }
@@ -1321,11 +1387,13 @@ int chol_potrf_probe(int tile, int reps, int stop_after, double* ms)
 }
 
 // S (tiles) is consumed, L goes to Lt; g is consumed; x receives the solution
+// tail (optional): the pose update of the trial rides in the one-launch backward substitution; *tail_done says whether it did
 int chol_factor_solve(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n, int* status,
-                      void* st)
+                      void* st, const PoseTail* tail, int* tail_done)
 {
     hipStream_t s = static_cast<hipStream_t>(st);
-    return p.TS == 48 ? run<48>(p, S, Lt, Linv, g, x, lambda, n, status, s) : run<96>(p, S, Lt, Linv, g, x, lambda, n, status, s);
+    return p.TS == 48 ? run<48>(p, S, Lt, Linv, g, x, lambda, n, status, s, tail, tail_done)
+                      : run<96>(p, S, Lt, Linv, g, x, lambda, n, status, s, tail, tail_done);
 }
 
 } // namespace svi

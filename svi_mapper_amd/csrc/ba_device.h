@@ -150,6 +150,18 @@ struct ChainInline { int n; int pad[3]; ChainRec c[kInlineCols]; };             
 struct SolveRec { int k, nq; int tile[kInlineSub], row[kInlineSub]; };
 struct SolveInline { int n; int pad[3]; SolveRec c[kInlineCols]; };
 
+// The pose update of a trial (g2o VertexSE3::oplusImpl + the pose part of computeScale), run by one extra workgroup of the
+// one-launch backward substitution: it waits for its dx entries like the column workgroups wait for theirs (src == nullptr: off)
+struct PoseTail {
+    const double* src; double* dst;   // pose [cur], pose [cur ^ 1]
+    const int* pose_red;              // [Pn] reduced index or -1 (fixed)
+    const double* bp;                 // [6 Pf]
+    double* scal;                     // scal[3] <- sum dx (wl dx + wb b_p); scal[8], [9] <- red_base[0], [1] if lin_from_red
+    const double* red_base;
+    int Pn, lin_from_red;
+    double wl, wb;
+};
+
 struct CholPlan {
     int TS = 0, NT = 0, n_steps = 0;
     // host: ranges of one dependency level (= one launch) in the device lists

@@ -18,6 +18,7 @@
 #include <chrono>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <functional>
 #include <numeric>
@@ -45,7 +46,7 @@ void ba_debug_aux_jacobians(const BaDev& d, int cur, double* se3_err, double* se
 void ba_configure_kernels(int TS);
 int chol_potrf_probe(int tile, int reps, int stop_after, double* ms);
 int chol_factor_solve(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n,
-                      int* status, void* st);
+                      int* status, void* st, const PoseTail* tail, int* tail_done);
 int build_structure(svi_ba* ba); // ba_structure.cpp
 int reupload_state(svi_ba* ba);
 
@@ -242,11 +243,20 @@ int trial(svi_ba* ba, double lambda, bool* failed)
     SVI_HIP(hipGetLastError());
     SVI_TRY(allreduce(ba, ba->lin_local ? d.red_base : d.g, (size_t)d.red_count + (ba->lin_local ? 2 : 0)));
     t.begin(SVI_PH_CHOLESKY, s);
-    if (d.NT > 0 && chol_factor_solve(ba->plan, d.S, d.Lt, d.Linv, d.g, d.dx, lambda, 6 * d.Pf, d.chol_status, s) != 0)
+    // the trial poses ride in the last launch of the solve (an extra workgroup that waits for its dx entries): a launch of their
+    // own was 5 us + a boundary between the backward substitution and the landmark back-substitution (not while phases are timed)
+    const int scale_mode = ba->opt.n_ranks <= 1 ? 0 : (ba->lin_local ? 2 : 1);
+    PoseTail tail{};
+    tail.src = d.pose[ba->cur]; tail.dst = d.pose[ba->cur ^ 1]; tail.pose_red = d.pose_red; tail.bp = d.bp; tail.scal = d.scal;
+    tail.red_base = d.red_base; tail.Pn = d.Pn; tail.lin_from_red = d.lin_from_red;
+    tail.wl = (scale_mode == 0 || ba->opt.rank == 0) ? lambda : 0.0; tail.wb = (scale_mode == 1 && ba->opt.rank != 0) ? 0.0 : 1.0;
+    int tail_done = 0;
+    static const bool no_tail = getenv("SVI_NO_POSE_TAIL") != nullptr; // (A/B timing)
+    if (d.NT > 0 && chol_factor_solve(ba->plan, d.S, d.Lt, d.Linv, d.g, d.dx, lambda, 6 * d.Pf, d.chol_status, s, (t.on || no_tail) ? nullptr : &tail, &tail_done) != 0)
         return fail(SVI_ERR_HIP, "Cholesky kernels could not be configured (LDS request refused)");
     t.end(s);
     t.begin(SVI_PH_BACKSUB_UPDATE, s);
-    ba_update_poses(d, ba->cur, lambda, ba->opt.n_ranks <= 1 ? 0 : (ba->lin_local ? 2 : 1), ba->opt.rank, s);
+    if (!tail_done) ba_update_poses(d, ba->cur, lambda, scale_mode, ba->opt.rank, s);
     ba_backsub_chi2(d, ba->cur, lambda, s);
     t.end(s);
     SVI_TRY(reduce_and_read_trial(ba, 12, ba->cur ^ 1)); // (evaluates the pose-only edges of the trial state itself)

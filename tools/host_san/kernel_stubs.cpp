@@ -22,5 +22,5 @@ void ba_debug_aux_jacobians(const BaDev&, int, double*, double*, double*, double
 void ba_gather_edges(const double*, const uint8_t*, const int*, const int*, int, int, int, double*, uint8_t*, const int*, int*, void*) {}
 void ba_configure_kernels(int) {}
 int chol_potrf_probe(int, int, int, double*) { return 0; }
-int chol_factor_solve(const CholPlan&, double*, double*, double*, double*, double*, double, int, int*, void*) { return 0; }
+int chol_factor_solve(const CholPlan&, double*, double*, double*, double*, double*, double, int, int*, void*, const PoseTail*, int* done) { if (done) *done = 0; return 0; }
 } // namespace svi
