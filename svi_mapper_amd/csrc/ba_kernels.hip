@@ -1028,15 +1028,26 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(BaDev d)
         double v[NE];
 #pragma unroll
         for (int k = 0; k < NE; ++k) v[k] = 0.0;
+        // the list bounds of the four cells and this wave's first two job indices of each travel together, in front of the cell
+        // loop: index -> slabs was two dependent round trips per cell, four cells one after the other
+        int cp[5], qa0[4], qb0[4];
+#pragma unroll
+        for (int c = 0; c < 5; ++c) cp[c] = d.cell_qj_ptr[4 * sub + c];
+#pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const int cell = 4 * sub + c;
+            const int x = cp[c] + w, xe = cp[c + 1];
+            qa0[c] = d.cell_qj[x < xe ? x : (xe > cp[c] ? xe - 1 : 0)];
+            qb0[c] = d.cell_qj[x + NWA < xe ? x + NWA : (x < xe ? x : (xe > cp[c] ? xe - 1 : 0))];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
             double pv[NE];
 #pragma unroll
             for (int k = 0; k < NE; ++k) pv[k] = 0.0;
-            const int xe = d.cell_qj_ptr[cell + 1];
-            for (int x = d.cell_qj_ptr[cell] + w; x < xe; x += 2 * NWA) { // two of this wave's jobs per step: 18 loads in flight
-                const bool two = x + NWA < xe;
-                const int qa = d.cell_qj[x], qb = d.cell_qj[two ? x + NWA : x];
+            const int xe = cp[c + 1];
+            for (int x = cp[c] + w; x < xe; x += 2 * NWA) { // two of this wave's jobs per step: 18 loads in flight
+                const bool two = x + NWA < xe, first = x == cp[c] + w;
+                const int qa = first ? qa0[c] : d.cell_qj[x], qb = first ? qb0[c] : d.cell_qj[two ? x + NWA : x];
                 const double* sa = d.slab + (size_t)(qa >> 2) * 36 * 64 + (qa & 3) * 16;
                 const double* sb = d.slab + (size_t)(qb >> 2) * 36 * 64 + (qb & 3) * 16;
                 double wa[NE], wb[NE];
@@ -1045,7 +1056,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(BaDev d)
 #pragma unroll
                 for (int k = 0; k < NE; ++k) { pv[k] -= wa[k]; if (two) pv[k] -= wb[k]; }
             }
-            if (d.cell_qj_ptr[cell + 1] - d.cell_qj_ptr[cell] > 0) { // block-uniform
+            if (cp[c + 1] - cp[c] > 0) { // block-uniform
 #pragma unroll
                 for (int k = 0; k < NE; ++k) s_part[w][lane + 64 * k] = pv[k];
                 __syncthreads();

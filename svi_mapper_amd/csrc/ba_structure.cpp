@@ -865,6 +865,7 @@ int schur_work_lists(Build& b)
             while (k < qjobs.size() && qjobs[k].cell == c) { b.cell_qj.push_back(slot_of[k]); ++k; } // qjobs ascend in cell
         }
         b.cell_qj_ptr[n_cells] = (int)b.cell_qj.size();
+        b.cell_qj.push_back(0); // (k_assemble requests a clamped index for cells without jobs: the list is never empty)
     }
     std::vector<std::vector<int>> taux(b.n_sub);
     for (int k = 0; k < (int)b.se3_i.size(); ++k) {
