@@ -115,6 +115,7 @@ struct BaDev {
     const int* qj_begin;     // [4 n_jobs] first item of quarter job 4 job + quarter
     const int* qj_end;       // [4 n_jobs]
     const int* qj_diag;      // [4 n_jobs] 1: diagonal cell (lower blocks only, carries g)
+    const int* job_merged;   // [n_jobs] 1: the four quarter jobs are pieces of one cell - the wave adds them up, quarter 0 carries the sum
     const int* job_len;      // [n_jobs] longest of the four quarter jobs
     double* slab;            // [n_jobs][36][64]  element q of the 6x6 block of lane (quarter = lane>>4, i = (lane>>2)&3, j = lane&3)
     double* gslab;           // [4 n_jobs][6][4]

@@ -991,6 +991,12 @@ __global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
         __builtin_amdgcn_wave_barrier();
         SCHUR_PIN
     }
+    if (d.job_merged[job]) { // (wave-uniform) four pieces of one cell: (q0 + q1) + (q2 + q3) in every lane, read from quarter 0
+#pragma unroll
+        for (int q = 0; q < 36; ++q) { double v = acc[q]; v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); acc[q] = v; }
+#pragma unroll
+        for (int q = 0; q < 6; ++q) { double v = gacc[q]; v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); gacc[q] = v; }
+    }
     double* out = d.slab + (size_t)job * 36 * 64;
 #pragma unroll
     for (int q = 0; q < 36; ++q) out[q * 64 + lane] = acc[q];

@@ -99,7 +99,7 @@ struct Build {
     // Schur
     int n_sub = 0, n_items = 0, n_jobs = 0;
     int64_t total_pairs = 0;
-    std::vector<int> sub_cx, sub_cy, sub_tile, it_pack, qj_begin, qj_end, qj_diag, job_len, cell_qj_ptr, cell_qj, sub_aux_ptr, sub_aux_ref;
+    std::vector<int> sub_cx, sub_cy, sub_tile, it_pack, qj_begin, qj_end, qj_diag, job_len, job_merged, cell_qj_ptr, cell_qj, sub_aux_ptr, sub_aux_ref;
 
     // the context lives in the handle: the vectors keep their memory from one svi_ba_initialize to the next (a fresh 15 MB
     // vector costs up to 3 ms of page faults on a busy box), so every one of them is emptied here (list generated from the
@@ -116,7 +116,7 @@ struct Build {
         diag_tile.clear(); level.clear(); h_step_ptr.clear(); step_col.clear(); pre_ptr.clear(); pre_tile.clear();
         pre_col.clear(); h_tgt_ptr.clear(); tgt_tile.clear(); tgt_row.clear(); tgt_pair_ptr.clear(); pair_a.clear();
         pair_b.clear(); pair_src.clear(); h_trsm_ptr.clear(); st_tile.clear(); st_col.clear(); sub_cx.clear(); sub_cy.clear();
-        sub_tile.clear(); it_pack.clear(); qj_begin.clear(); qj_end.clear(); qj_diag.clear(); job_len.clear();
+        sub_tile.clear(); it_pack.clear(); qj_begin.clear(); qj_end.clear(); qj_diag.clear(); job_len.clear(); job_merged.clear();
         cell_qj_ptr.clear(); cell_qj.clear(); sub_aux_ptr.clear(); sub_aux_ref.clear();
         Pn = Pf = Ltot = 0; Etot = 0; use_cpl = false; span = 0; L0 = Ll = E = Epm = 0; n_lm_blocks = n_chunks = 0; planes = 3;
         TS = 96; PB = 16; n = NT = n_tiles = n_tiles_orig = n_steps = 0; chol_flops = 0.0; n_sub = n_items = n_jobs = 0; total_pairs = 0;
@@ -846,7 +846,7 @@ int schur_work_lists(Build& b)
     const size_t nq4 = (size_t)4 * std::max(b.n_jobs, 1);
     b.qj_begin.assign(nq4, 0); b.qj_end.assign(nq4, 0); b.qj_diag.assign(nq4, 0);
     b.job_len.assign(std::max(b.n_jobs, 1), 0);
-    std::vector<int> slot_of(qjobs.size(), -1);
+    std::vector<int> slot_of(qjobs.size(), -1), slot_cell(nq4, -1);
     for (int x = 0; x < NX; ++x)
         for (size_t j = 0; j < xq[x].size(); ++j) {
             const QJob& q = qjobs[xq[x][j]];
@@ -856,13 +856,26 @@ int schur_work_lists(Build& b)
             b.qj_diag[k] = (b.sub_cx[sub] == b.sub_cy[sub] && u == v) ? 1 : 0;
             b.job_len[k / 4] = std::max(b.job_len[k / 4], q.end - q.begin);
             slot_of[xq[x][j]] = (int)k;
+            slot_cell[k] = q.cell;
         }
+    // A wave whose four quarter jobs belong to ONE cell (the full-length pieces of a hot cell are neighbours in the sorted lists)
+    // adds its quarters up itself and leaves one slab instead of four: k_assemble walks a quarter of the list of a hot cell
+    // (forty pieces of a diagonal cell was what its slowest workgroups waited for).  The order of the sums stays fixed.
+    b.job_merged.assign(std::max(b.n_jobs, 1), 0);
+    for (int job = 0; job < b.n_jobs; ++job) {
+        const int c0 = slot_cell[(size_t)4 * job];
+        b.job_merged[job] = (c0 >= 0 && slot_cell[(size_t)4 * job + 1] == c0 && slot_cell[(size_t)4 * job + 2] == c0 && slot_cell[(size_t)4 * job + 3] == c0) ? 1 : 0;
+    }
     b.cell_qj_ptr.assign((size_t)n_cells + 1, 0);
     {
         size_t k = 0;
         for (int c = 0; c < n_cells; ++c) {
             b.cell_qj_ptr[c] = (int)b.cell_qj.size();
-            while (k < qjobs.size() && qjobs[k].cell == c) { b.cell_qj.push_back(slot_of[k]); ++k; } // qjobs ascend in cell
+            while (k < qjobs.size() && qjobs[k].cell == c) { // qjobs ascend in cell
+                const int slot = slot_of[k];
+                if (!(b.job_merged[slot >> 2] && (slot & 3) != 0)) b.cell_qj.push_back(slot); // (a merged wave: its first quarter carries the sum)
+                ++k;
+            }
         }
         b.cell_qj_ptr[n_cells] = (int)b.cell_qj.size();
         b.cell_qj.push_back(0); // (k_assemble requests a clamped index for cells without jobs: the list is never empty)
@@ -983,6 +996,7 @@ int upload(Build& b)
     SVI_TRY(up.up(b.qj_begin, &d.qj_begin));
     SVI_TRY(up.up(b.qj_end, &d.qj_end));
     SVI_TRY(up.up(b.qj_diag, &d.qj_diag));
+    SVI_TRY(up.up(b.job_merged, &d.job_merged));
     SVI_TRY(up.up(b.job_len, &d.job_len));
     SVI_TRY(up.alloc((size_t)std::max(n_jobs, 1) * 36 * 64, &d.slab, false));
     SVI_TRY(up.alloc((size_t)std::max(n_jobs, 1) * 4 * 6 * 4, &d.gslab, false));
