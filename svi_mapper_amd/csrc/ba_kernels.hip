@@ -991,16 +991,19 @@ __global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
         __builtin_amdgcn_wave_barrier();
         SCHUR_PIN
     }
-    if (d.job_merged[job]) { // (wave-uniform) four pieces of one cell: (q0 + q1) + (q2 + q3) in every lane, read from quarter 0
+    if (d.job_merged[job] != 0) { // (wave-uniform) four pieces of one cell: (q0 + q1) + (q2 + q3) in every lane, read from quarter 0
 #pragma unroll
         for (int q = 0; q < 36; ++q) { double v = acc[q]; v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); acc[q] = v; }
 #pragma unroll
         for (int q = 0; q < 6; ++q) { double v = gacc[q]; v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); gacc[q] = v; }
     }
+    const bool merged = d.job_merged[job] != 0;
     double* out = d.slab + (size_t)job * 36 * 64;
+    if (!merged || qt == 0) { // (a merged wave: only its first quarter is ever read)
 #pragma unroll
-    for (int q = 0; q < 36; ++q) out[q * 64 + lane] = acc[q];
-    if (diag && i == j) {
+        for (int q = 0; q < 36; ++q) out[q * 64 + lane] = acc[q];
+    }
+    if (diag && i == j && (!merged || qt == 0)) {
 #pragma unroll
         for (int q = 0; q < 6; ++q) d.gslab[((size_t)(4 * job + qt) * 6 + q) * 4 + i] = gacc[q];
     }

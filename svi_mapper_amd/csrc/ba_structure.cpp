@@ -866,6 +866,11 @@ int schur_work_lists(Build& b)
         const int c0 = slot_cell[(size_t)4 * job];
         b.job_merged[job] = (c0 >= 0 && slot_cell[(size_t)4 * job + 1] == c0 && slot_cell[(size_t)4 * job + 2] == c0 && slot_cell[(size_t)4 * job + 3] == c0) ? 1 : 0;
     }
+    if (b.dbg) {
+        int nm = 0, nonempty = 0;
+        for (int job = 0; job < b.n_jobs; ++job) { nm += b.job_merged[job]; nonempty += b.job_len[job] > 0; }
+        fprintf(stderr, "schur: %d jobs (%d with work), %d of them single-cell (merged slabs), piece length %d\n", b.n_jobs, nonempty, nm, L);
+    }
     b.cell_qj_ptr.assign((size_t)n_cells + 1, 0);
     {
         size_t k = 0;
