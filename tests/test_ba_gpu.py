@@ -94,6 +94,24 @@ def test_single_iteration_matches(svi, oracle, small, tile):
     assert abs(g.last_plain_chi2 - o.last_plain_chi2) <= 1e-8 * o.last_plain_chi2
 
 
+def test_more_poses_than_one_workgroup_has_lanes(svi, oracle):
+    """700 key frames: the trial poses (an extra workgroup of the one-launch backward substitution, one lane per pose) and the
+    XCD-wise placement of the Schur work both loop / split where config 4 (500 key frames) does not."""
+    prob = synth.make_ba_problem(700, 5000, 30000, seed=0x2BC)
+    g, _ = _make(svi.BundleAdjuster, prob)
+    o, _ = _make(oracle.OracleBA, prob)
+    g.initialize()
+    o.initialize()
+    for n in (1, 3):
+        assert g.optimize(n) == o.optimize(n)
+    _, Tg = g.get_poses()
+    _, To = o.get_poses()
+    _, pg = g.get_landmarks()
+    _, po = o.get_landmarks()
+    assert _rel(Tg, To) < 1e-9 and _rel(pg, po) < 1e-9
+    assert abs(g.last_plain_chi2 - o.last_plain_chi2) <= 1e-8 * o.last_plain_chi2
+
+
 def _full_schedule(svi, oracle, prob, **kw):
     g, _ = _make(svi.BundleAdjuster, prob, **kw)
     o, _ = _make(oracle.OracleBA, prob)
