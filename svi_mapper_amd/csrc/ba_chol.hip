@@ -1204,6 +1204,8 @@ __global__ __launch_bounds__(kPotrfThreads) void k_back_solve_all(const SolveRec
 #pragma unroll
         for (int w = 0; w < RB; ++w) lv[s][w] = 0.0;
         if (u < nq * NRB) { // uniform
+            // (the record lists the rows by level, highest first: what was solved long ago is polled first, the row of the level just
+            // above - the last to arrive - last; polled first it kept the finished ones waiting behind it: 32.9 -> 27.9 us)
             const int q = u / NRB, rb = u % NRB;
             const double* L = Lt + (size_t)rec->tile[q] * TS * TS + (size_t)rb * RB * TS;
             xsrc[s] = x + (size_t)rec->row[q] * TS + rb * RB + (lane < RB ? lane : 0);

@@ -1072,13 +1072,23 @@ int upload(Build& b)
         {   // the same records once more, for the one-launch backward substitution: levels n_steps-2 .. 0, a column per workgroup
             std::vector<SolveRec> recs;
             bool ok = TS == 48 && b.n_steps >= 2;
+            std::vector<int> lvl((size_t)NT, 0); // dependency level of every tile column
+            for (int st = 0; st < b.n_steps; ++st)
+                for (int q = b.h_step_ptr[st]; q < b.h_step_ptr[st + 1]; ++q) lvl[b.step_col[q]] = st;
             for (int st = b.n_steps - 2; st >= 0 && ok; --st)
                 for (int q = b.h_step_ptr[st]; q < b.h_step_ptr[st + 1]; ++q) {
                     const int c = b.step_col[q], nq = b.h_col_ptr[c + 1] - b.h_col_ptr[c];
                     if (nq > kInlineSub) { ok = false; break; }
                     SolveRec r{};
                     r.k = c; r.nq = nq;
-                    for (int w = 0; w < nq; ++w) { r.tile[w] = b.trsm_tile[b.h_col_ptr[c] + w]; r.row[w] = b.trsm_row[b.h_col_ptr[c] + w]; }
+                    // rows by level, highest first (= the order in which their x arrives in the backward substitution)
+                    int ord[kInlineSub];
+                    for (int w = 0; w < nq; ++w) ord[w] = b.h_col_ptr[c] + w;
+                    std::sort(ord, ord + nq, [&](int x, int y) {
+                        const int lx = lvl[b.trsm_row[x]], ly = lvl[b.trsm_row[y]];
+                        return lx != ly ? lx > ly : b.trsm_row[x] > b.trsm_row[y];
+                    });
+                    for (int w = 0; w < nq; ++w) { r.tile[w] = b.trsm_tile[ord[w]]; r.row[w] = b.trsm_row[ord[w]]; }
                     recs.push_back(r);
                 }
             p.solve_recs = nullptr; p.n_solve_cols = 0; p.ybuf = nullptr;
