@@ -165,7 +165,26 @@ int read_scalars(svi_ba* ba, int n)
 // kernel publishes them itself
 // aux_state: the state whose pose-only edges the reduction evaluates itself (-1: their sums are already in scal[6..7]);
 // a linearisation whose closing sums were deferred (linearize) has them taken here as well
-int reduce_and_read_trial(svi_ba* ba, int n, int aux_state)
+// The part of a linearisation that needs nothing from the host: Jacobian sweep (K2 + K3) and the pose-only edges of `state`.
+void enqueue_sweep(svi_ba* ba, int state)
+{
+    BaDev& d = ba->d;
+    hipStream_t s = ba->stream;
+    PhaseTimer& t = ba->timer;
+    ba->sweep_timer.begin(0, s);
+    t.begin(SVI_PH_LINEARIZE_LM, s);   ba_linearize_lm(d, state, s);   t.end(s);
+    t.begin(SVI_PH_LINEARIZE_POSE, s); ba_linearize_pose(d, state, s); t.end(s);
+    ba->sweep_timer.end(s);
+    t.begin(SVI_PH_POSE_EDGES, s);
+    ba_linearize_aux(d, state, ba->opt.rank, s);
+    // (the caller closes SVI_PH_POSE_EDGES behind the pose sums)
+}
+
+// spec_state >= 0: while the host waits for the trial's numbers the device already runs the sweep of that state - the
+// linearisation of the NEXT iteration if the trial is accepted (it nearly always is).  The host round trip (read, LM rule,
+// launch: 12-25 us) then hides behind 58 us of kernels instead of leaving the device idle.  A rejected trial finds the
+// buffers of its linearisation overwritten and linearises its state again (optimize_block).
+int reduce_and_read_trial(svi_ba* ba, int n, int aux_state, int spec_state = -1)
 {
     const int with_lin = ba->lin_post_deferred ? 1 : 0;
     ba->lin_post_deferred = false;
@@ -173,6 +192,7 @@ int reduce_and_read_trial(svi_ba* ba, int n, int aux_state)
     if (ba->opt.n_ranks == 1 && !ba->timer.on) {
         const int seq = ++ba->pub_seq;
         ba_reduce_trial_scalars(ba->d, aux_state, with_lin, n, ba->h_scal, ba->h_status, seq, ba->stream);
+        if (spec_state >= 0) { enqueue_sweep(ba, spec_state); ba->spec_lin_state = spec_state; }
         SVI_HIP(hipGetLastError());
         return wait_published(ba, seq);
     }
@@ -189,12 +209,8 @@ int linearize(svi_ba* ba, bool read = true)
     BaDev& d = ba->d;
     hipStream_t s = ba->stream;
     PhaseTimer& t = ba->timer;
-    ba->sweep_timer.begin(0, s);
-    t.begin(SVI_PH_LINEARIZE_LM, s);   ba_linearize_lm(d, ba->cur, s);   t.end(s);
-    t.begin(SVI_PH_LINEARIZE_POSE, s); ba_linearize_pose(d, ba->cur, s); t.end(s);
-    ba->sweep_timer.end(s);
-    t.begin(SVI_PH_POSE_EDGES, s);
-    ba_linearize_aux(d, ba->cur, ba->opt.rank, s);
+    if (ba->spec_lin_state != ba->cur) enqueue_sweep(ba, ba->cur); // (else: enqueued behind the previous trial's reduction)
+    ba->spec_lin_state = -1;
     // lambda of the trial that follows is known unless this is the first linearisation of a block (lambda_0 needs max H_jj):
     // the landmark blocks are then inverted in the same launch
     ba->hinv_valid = !read && d.Ll > 0;
@@ -228,7 +244,7 @@ void assemble(svi_ba* ba)
     ba_assemble(d, ba->stream);
 }
 
-int trial(svi_ba* ba, double lambda, bool* failed)
+int trial(svi_ba* ba, double lambda, bool* failed, bool speculate = false)
 {
     BaDev& d = ba->d;
     hipStream_t s = ba->stream;
@@ -252,6 +268,7 @@ int trial(svi_ba* ba, double lambda, bool* failed)
     tail.wl = (scale_mode == 0 || ba->opt.rank == 0) ? lambda : 0.0; tail.wb = (scale_mode == 1 && ba->opt.rank != 0) ? 0.0 : 1.0;
     int tail_done = 0;
     static const bool no_tail = getenv("SVI_NO_POSE_TAIL") != nullptr; // (A/B timing)
+    static const bool no_spec = getenv("SVI_NO_SPECULATION") != nullptr;
     if (d.NT > 0 && chol_factor_solve(ba->plan, d.S, d.Lt, d.Linv, d.g, d.dx, lambda, 6 * d.Pf, d.chol_status, s, (t.on || no_tail) ? nullptr : &tail, &tail_done) != 0)
         return fail(SVI_ERR_HIP, "Cholesky kernels could not be configured (LDS request refused)");
     t.end(s);
@@ -259,7 +276,9 @@ int trial(svi_ba* ba, double lambda, bool* failed)
     if (!tail_done) ba_update_poses(d, ba->cur, lambda, scale_mode, ba->opt.rank, s);
     ba_backsub_chi2(d, ba->cur, lambda, s);
     t.end(s);
-    SVI_TRY(reduce_and_read_trial(ba, 12, ba->cur ^ 1)); // (evaluates the pose-only edges of the trial state itself)
+    // (evaluates the pose-only edges of the trial state itself)
+    const bool spec = speculate && ba->opt.n_ranks == 1 && !t.on && !no_spec;
+    SVI_TRY(reduce_and_read_trial(ba, 12, ba->cur ^ 1, spec ? (ba->cur ^ 1) : -1));
     // with several ranks the landmark blocks (and so the status word) are local: a failure anywhere arrives as a
     // non-finite chi2 through the all-reduce, so every rank takes the same branch of the LM rule
     *failed = ba->h_status[0] != 0 || (ba->opt.n_ranks > 1 && !std::isfinite(ba->h_scal[0]));
@@ -314,6 +333,7 @@ int optimize_block(svi_ba* ba, int iterations, int* performed)
     SVI_HIP(svi::enter_device(ba->opt.device));
     const svi_ba_options& o = ba->opt;
     int done = 0;
+    ba->spec_lin_state = -1; // (the state may have been edited since the last block)
     for (int it = 0; it < iterations; ++it) {
         // Only the first iteration of a block needs the linearisation results on the host before the trial can be
         // launched (lambda_0 = tau * max H_jj); afterwards lambda is known and the host reads chi2 of the linearisation
@@ -332,7 +352,9 @@ int optimize_block(svi_ba* ba, int iterations, int* performed)
         bool stop_inf = false;
         do {
             bool failed = false;
-            SVI_TRY(trial(ba, ba->lambda, &failed));
+            // a rejected trial whose speculative successor sweep has overwritten this iteration's linearisation: once more
+            if (ba->spec_lin_state >= 0 && ba->spec_lin_state != ba->cur) { ba->spec_lin_state = -1; SVI_TRY(linearize(ba, false)); }
+            SVI_TRY(trial(ba, ba->lambda, &failed, it + 1 < iterations));
             if (!have_lin) {
                 chi = ba->h_scal[8];
                 ba->last_robust = chi; ba->last_plain = ba->h_scal[9]; ba->have_chi = true;

@@ -64,6 +64,7 @@ struct svi_ba {
 
     // ---- device ----
     hipStream_t stream = nullptr;
+    int spec_lin_state = -1;   // state whose Jacobian sweep + pose-only edges are already enqueued (speculation on "accepted"), or -1
     bool own_stream = false;
     bool host_stale = false; // an optimize() has run since the host copy of the estimates was refreshed (ensure_host)
     bool lin_local = false; // several ranks: the last linearisation kept its pose sums local (see linearize())
