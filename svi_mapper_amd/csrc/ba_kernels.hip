@@ -530,10 +530,14 @@ __global__ __launch_bounds__(kAuxThreads) void k_aux_edges(BaDev d, int which)
         double e[6], Ji[36], Jj[36], O[36];
         se3_edge_eval(pose + 12 * si, pose + 12 * sj, d.se3_Z + 12 * k, e, LINEARIZE ? Ji : nullptr, Jj);
         int q = 0;
+#pragma unroll
         for (int r = 0; r < 6; ++r)
+#pragma unroll
             for (int c = r; c < 6; ++c, ++q) O[6 * r + c] = O[6 * c + r] = d.se3_info[21 * k + q];
         double c2 = 0.0;
+#pragma unroll
         for (int r = 0; r < 6; ++r)
+#pragma unroll
             for (int c = 0; c < 6; ++c) c2 += e[r] * O[6 * r + c] * e[c];
         double w = 1.0, r0 = c2;
         if (d.se3_robust[k]) cauchy(d.cauchy_delta, c2, r0, w);
@@ -541,19 +545,26 @@ __global__ __launch_bounds__(kAuxThreads) void k_aux_edges(BaDev d, int which)
         if (LINEARIZE) {
             double* out = d.se3_out + (size_t)120 * k;
             double Oe[6], OJi[36], OJj[36];
+#pragma unroll
             for (int r = 0; r < 6; ++r) {
                 double sacc = 0.0;
+#pragma unroll
                 for (int c = 0; c < 6; ++c) sacc += w * O[6 * r + c] * e[c];
                 Oe[r] = sacc;
+#pragma unroll
                 for (int c = 0; c < 6; ++c) {
                     double a = 0.0, b = 0.0;
+#pragma unroll
                     for (int m = 0; m < 6; ++m) { a += w * O[6 * r + m] * Ji[6 * m + c]; b += w * O[6 * r + m] * Jj[6 * m + c]; }
                     OJi[6 * r + c] = a; OJj[6 * r + c] = b;
                 }
             }
+#pragma unroll
             for (int r = 0; r < 6; ++r)
+#pragma unroll
                 for (int c = 0; c < 6; ++c) {
                     double hii = 0.0, hjj = 0.0, hij = 0.0;
+#pragma unroll
                     for (int m = 0; m < 6; ++m) {
                         hii += Ji[6 * m + r] * OJi[6 * m + c];
                         hjj += Jj[6 * m + r] * OJj[6 * m + c];
@@ -561,8 +572,10 @@ __global__ __launch_bounds__(kAuxThreads) void k_aux_edges(BaDev d, int which)
                     }
                     out[6 * r + c] = hii; out[36 + 6 * r + c] = hjj; out[72 + 6 * r + c] = hij;
                 }
+#pragma unroll
             for (int r = 0; r < 6; ++r) {
                 double bi = 0.0, bj = 0.0;
+#pragma unroll
                 for (int m = 0; m < 6; ++m) { bi += Ji[6 * m + r] * Oe[m]; bj += Jj[6 * m + r] * Oe[m]; }
                 out[108 + r] = -bi; out[114 + r] = -bj;
             }
@@ -574,6 +587,7 @@ __global__ __launch_bounds__(kAuxThreads) void k_aux_edges(BaDev d, int which)
         double e[3], J[18];
         accel_edge_eval(R, v, e, LINEARIZE ? J : nullptr);
         double O[6];
+#pragma unroll
         for (int q = 0; q < 6; ++q) O[q] = d.acc_info[6 * k + q];
         const double c2 = e[0] * (O[0] * e[0] + 2.0 * (O[1] * e[1] + O[2] * e[2])) + e[1] * (O[3] * e[1] + 2.0 * O[4] * e[2]) +
                           e[2] * O[5] * e[2];
@@ -581,15 +595,21 @@ __global__ __launch_bounds__(kAuxThreads) void k_aux_edges(BaDev d, int which)
         if (LINEARIZE) {
             const double Of[9] = {O[0], O[1], O[2], O[1], O[3], O[4], O[2], O[4], O[5]};
             double* out = d.acc_out + (size_t)42 * k;
+#pragma unroll
             for (int r = 0; r < 6; ++r) {
+#pragma unroll
                 for (int c = 0; c < 6; ++c) {
                     double h = 0.0;
+#pragma unroll
                     for (int m = 0; m < 3; ++m)
+#pragma unroll
                         for (int n = 0; n < 3; ++n) h += J[6 * m + r] * Of[3 * m + n] * J[6 * n + c];
                     out[6 * r + c] = h;
                 }
                 double bb = 0.0;
+#pragma unroll
                 for (int m = 0; m < 3; ++m)
+#pragma unroll
                     for (int n = 0; n < 3; ++n) bb += J[6 * m + r] * Of[3 * m + n] * e[n];
                 out[36 + r] = -bb;
             }
@@ -629,10 +649,14 @@ __device__ __forceinline__ void aux_edges_chi2(const BaDev& d, const double* __r
         double e[6], O[36];
         se3_edge_eval(pose + 12 * si, pose + 12 * sj, d.se3_Z + 12 * k, e, nullptr, nullptr);
         int q = 0;
+#pragma unroll
         for (int r = 0; r < 6; ++r)
+#pragma unroll
             for (int c = r; c < 6; ++c, ++q) O[6 * r + c] = O[6 * c + r] = d.se3_info[21 * k + q];
         double c2 = 0.0;
+#pragma unroll
         for (int r = 0; r < 6; ++r)
+#pragma unroll
             for (int c = 0; c < 6; ++c) c2 += e[r] * O[6 * r + c] * e[c];
         double w = 1.0, r0 = c2;
         if (d.se3_robust[k]) cauchy(d.cauchy_delta, c2, r0, w);
@@ -644,6 +668,7 @@ __device__ __forceinline__ void aux_edges_chi2(const BaDev& d, const double* __r
         double e[3];
         accel_edge_eval(R, v, e, nullptr);
         double O[6];
+#pragma unroll
         for (int q = 0; q < 6; ++q) O[q] = d.acc_info[6 * k + q];
         const double c2 = e[0] * (O[0] * e[0] + 2.0 * (O[1] * e[1] + O[2] * e[2])) + e[1] * (O[3] * e[1] + 2.0 * O[4] * e[2]) +
                           e[2] * O[5] * e[2];

@@ -153,14 +153,25 @@ SVI_HD void R_to_quat(const double* m, double* q)
         t = sqrt(t + 1.0); w = 0.5 * t; t = 0.5 / t;
         v[0] = (m[7] - m[5]) * t; v[1] = (m[2] - m[6]) * t; v[2] = (m[3] - m[1]) * t;
     } else {
+        // (i, j, k) = the largest diagonal entry and its cyclic successors.  Written out per case: indexing m with i, j, k puts
+        // the matrix - a register array of the caller - into scratch memory on the GPU (every access a memory round trip: the
+        // pose-only edge kernels spent most of their 11 us there)
+        const double m0 = m[0], m1 = m[1], m2 = m[2], m3 = m[3], m4 = m[4], m5 = m[5], m6 = m[6], m7 = m[7], m8 = m[8]; // (values, not addresses)
         int i = 0;
-        if (m[4] > m[0]) i = 1;
-        if (m[8] > m[4 * i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(m[4 * i] - m[4 * j] - m[4 * k] + 1.0);
+        if (m4 > m0) i = 1;
+        if (m8 > (i == 1 ? m4 : m0)) i = 2;
+        const int j = (i + 1) % 3;
+        const double mii = i == 0 ? m0 : i == 1 ? m4 : m8;
+        const double mjj = i == 0 ? m4 : i == 1 ? m8 : m0;
+        const double mkk = i == 0 ? m8 : i == 1 ? m0 : m4;
+        t = sqrt(mii - mjj - mkk + 1.0);
         double vi = 0.5 * t; t = 0.5 / t;
-        w = (m[3 * k + j] - m[3 * j + k]) * t;
-        double vj = (m[3 * j + i] + m[3 * i + j]) * t, vk = (m[3 * k + i] + m[3 * i + k]) * t;
+        const double d0 = m7 - m5, d1 = m2 - m6, d2 = m3 - m1; // m[3k+j] - m[3j+k] for i = 0, 1, 2
+        const double s0 = m3 + m1, s1 = m7 + m5, s2 = m2 + m6; // m[3j+i] + m[3i+j]
+        const double u0 = m6 + m2, u1 = m1 + m3, u2 = m5 + m7; // m[3k+i] + m[3i+k]
+        w = (i == 0 ? d0 : i == 1 ? d1 : d2) * t;
+        double vj = (i == 0 ? s0 : i == 1 ? s1 : s2) * t;
+        double vk = (i == 0 ? u0 : i == 1 ? u1 : u2) * t;
         v[0] = (i == 0) ? vi : ((j == 0) ? vj : vk);
         v[1] = (i == 1) ? vi : ((j == 1) ? vj : vk);
         v[2] = (i == 2) ? vi : ((j == 2) ? vj : vk);
@@ -174,15 +185,21 @@ SVI_HD void R_to_quat(const double* m, double* q)
 SVI_HD void mat3_mul(const double* A, const double* B, double* C)
 {
     double r[9];
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j) r[3 * i + j] = A[3 * i] * B[j] + A[3 * i + 1] * B[3 + j] + A[3 * i + 2] * B[6 + j];
+#pragma unroll
     for (int k = 0; k < 9; ++k) C[k] = r[k];
 }
 SVI_HD void mat3T_mul(const double* A, const double* B, double* C)
 {
     double r[9];
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j) r[3 * i + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+#pragma unroll
     for (int k = 0; k < 9; ++k) C[k] = r[k];
 }
 
@@ -214,11 +231,15 @@ SVI_HD void se3_edge_eval(const double* Xi, const double* Xj, const double* Z, d
         tb[2] = Ri[2] * d0 + Ri[5] * d1 + Ri[8] * d2;
     }
     double Ra[9], ta[3];
+#pragma unroll
     for (int i = 0; i < 3; ++i)
+#pragma unroll
         for (int j = 0; j < 3; ++j) Ra[3 * i + j] = Rz[3 * j + i];
+#pragma unroll
     for (int i = 0; i < 3; ++i) ta[i] = -(Ra[3 * i] * tz[0] + Ra[3 * i + 1] * tz[1] + Ra[3 * i + 2] * tz[2]);
     double Re[9], te[3];
     mat3_mul(Ra, Rb, Re);
+#pragma unroll
     for (int i = 0; i < 3; ++i) te[i] = Ra[3 * i] * tb[0] + Ra[3 * i + 1] * tb[1] + Ra[3 * i + 2] * tb[2] + ta[i];
     double qe[4];
     R_to_quat(Re, qe);
@@ -232,27 +253,36 @@ SVI_HD void se3_edge_eval(const double* Xi, const double* Xj, const double* Z, d
     const double vq1 = qa[0] * qb[2] + qb[0] * qa[2] + (qa[3] * qb[1] - qa[1] * qb[3]);
     const double vq2 = qa[0] * qb[3] + qb[0] * qa[3] + (qa[1] * qb[2] - qa[2] * qb[1]);
     const double sgn = (wq * qe[0] + vq0 * qe[1] + vq1 * qe[2] + vq2 * qe[3]) < 0 ? -1.0 : 1.0;
+#pragma unroll
     for (int k = 0; k < 36; ++k) { Ji[k] = 0.0; Jj[k] = 0.0; }
+#pragma unroll
     for (int r = 0; r < 3; ++r)
+#pragma unroll
         for (int c = 0; c < 3; ++c) { Jj[6 * r + c] = Re[3 * r + c]; Ji[6 * r + c] = -Ra[3 * r + c]; }
     {
         const double we = qe[0], *ve = qe + 1;
         const double M[9] = {we, -ve[2], ve[1], ve[2], we, -ve[0], -ve[1], ve[0], we};
+#pragma unroll
         for (int r = 0; r < 3; ++r)
+#pragma unroll
             for (int c = 0; c < 3; ++c) Jj[6 * (3 + r) + 3 + c] = M[3 * r + c];
     }
     {
         const double S[9] = {0, -tb[2], tb[1], tb[2], 0, -tb[0], -tb[1], tb[0], 0};
         double RS[9];
         mat3_mul(Ra, S, RS);
+#pragma unroll
         for (int r = 0; r < 3; ++r)
+#pragma unroll
             for (int c = 0; c < 3; ++c) Ji[6 * r + 3 + c] = 2.0 * RS[3 * r + c];
         const double wa = qa[0], *va = qa + 1, wb = qb[0], *vb = qb + 1;
         const double Ma[9] = {wa, -va[2], va[1], va[2], wa, -va[0], -va[1], va[0], wa};
         const double Mb[9] = {wb, vb[2], -vb[1], -vb[2], wb, vb[0], vb[1], -vb[0], wb};
         double MM[9];
         mat3_mul(Mb, Ma, MM);
+#pragma unroll
         for (int r = 0; r < 3; ++r)
+#pragma unroll
             for (int c = 0; c < 3; ++c) Ji[6 * (3 + r) + 3 + c] = sgn * (vb[r] * va[c] - MM[3 * r + c]);
     }
 }
