@@ -42,7 +42,8 @@ typedef enum svi_status {
     SVI_ERR_UNSUPPORTED = 5, /* graph shape outside what the path supports */
     SVI_ERR_NOT_FOUND   = 6, /* vertex id not in graph */
     SVI_ERR_IO          = 7, /* .g2o file could not be read / written */
-    SVI_ERR_COMM        = 8  /* the all-reduce hook reported failure */
+    SVI_ERR_COMM        = 8, /* the all-reduce hook reported failure */
+    SVI_ERR_INTERNAL    = 9  /* a defect of the library itself was detected (e.g. a hand-over inside a launch timed out): the call failed, nothing was applied */
 } svi_status;
 
 const char* svi_status_string(int status);
@@ -650,6 +651,7 @@ int svi_ba_set_allreduce(svi_ba* ba, svi_allreduce_fn fn, void* user);
  *   rank 0:      svi_rccl_unique_id(id)  and hands the 128 bytes to the other ranks by whatever means the host has
  *   every rank:  svi_rccl_create(id, rank, n_ranks, device, &c);  svi_ba_set_allreduce(ba, svi_rccl_allreduce, c) */
 typedef struct svi_rccl svi_rccl;
+int svi_rccl_available(void); /* 1: librccl resolved in this process (no collective): let the ranks agree on it BEFORE svi_rccl_create */
 int svi_rccl_unique_id(void* id_out /* 128 bytes */);
 int svi_rccl_create(const void* unique_id, int rank, int n_ranks, int device, svi_rccl** out);
 int svi_rccl_destroy(svi_rccl* c);
@@ -687,6 +689,7 @@ typedef struct svi_ba_stats {
     int64_t reduce_doubles;                    /* payload of one all-reduce */
     double  chol_flops;                        /* of one factorisation on the tile structure */
     uint64_t lm_iterations, lm_trials, chol_failures;
+    uint64_t backsolve_timeouts;               /* trials ended by SVI_ERR_INTERNAL (never counted as chol_failures) */
 } svi_ba_stats;
 int svi_ba_get_stats(svi_ba* ba, svi_ba_stats* s);
 
@@ -718,6 +721,11 @@ int svi_ba_debug_time_sweep_cold(svi_ba* ba, int reps, size_t evict_bytes, doubl
  * block inverses, 4 +off-diagonal inverse blocks, 5 load only; 6: ms[0] = shader cycles and ms[1] = 100 MHz
  * ticks spent in the pivot sweep, ms must have room for 2 doubles) */
 int svi_debug_chol_probe(int device, int tile, int reps, int stop_after, double* ms);
+
+/* test knob: how many polls a workgroup of the one-launch backward substitution grants a pending entry (default 2^22).  With a
+ * tiny budget the hand-overs time out, and svi_ba_optimize must return SVI_ERR_INTERNAL instead of treating the trial as
+ * "not positive definite" (process-wide; restore the default afterwards) */
+int svi_debug_set_backsolve_spin_limit(int polls);
 
 #ifdef __cplusplus
 }

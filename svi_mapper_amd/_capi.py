@@ -106,7 +106,7 @@ class BaStats(C.Structure):
                  "n_edges_proj_local", "n_edges_se3", "n_edges_accel", "n_edges_lmlm", "n_schur_tiles",
                  "n_window_blocks", "chol_n", "chol_tile", "chol_tiles_nnz", "chol_steps", "reduce_doubles")] + \
                [("chol_flops", C.c_double), ("lm_iterations", C.c_uint64), ("lm_trials", C.c_uint64),
-                ("chol_failures", C.c_uint64)]
+                ("chol_failures", C.c_uint64), ("backsolve_timeouts", C.c_uint64)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, vp)
@@ -197,6 +197,8 @@ SIGNATURES = {
     "svi_ba_load_g2o": (C.c_int, [vp, C.c_char_p]),
     "svi_ba_save_g2o": (C.c_int, [vp, C.c_char_p]),
     "svi_ba_set_allreduce": (C.c_int, [vp, ALLREDUCE_FN, vp]),
+    "svi_debug_set_backsolve_spin_limit": (C.c_int, [C.c_int]),
+    "svi_rccl_available": (C.c_int, []),
     "svi_rccl_unique_id": (C.c_int, [vp]),
     "svi_rccl_create": (C.c_int, [vp, C.c_int, C.c_int, C.c_int, C.POINTER(vp)]),
     "svi_rccl_destroy": (C.c_int, [vp]),

@@ -18,6 +18,7 @@
 // when CHOLMOD reports "not positive definite".
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <cstdint>
 #include <vector>
 
@@ -25,6 +26,7 @@
 #include "ba_math.h"
 
 namespace svi {
+extern std::atomic<int> g_backsolve_spin_limit; // ba_host.cpp
 namespace {
 
 constexpr int kBlock = 256;
@@ -1101,17 +1103,21 @@ __global__ __launch_bounds__(kPotrfThreads) void k_back_solve_inl(SolveInline si
     }
 }
 
-// The WHOLE backward substitution in one launch: one workgroup per column below the last level, in descending level order
-// (block index order = dependency order, so a grid larger than the chip holds still makes progress).  A workgroup requests the
+// The WHOLE backward substitution in one launch: one workgroup per column below the last level, in descending level order.
+// Forward progress: a workgroup only ever waits for workgroups with a LOWER block index (higher level), and the host uses this
+// launch only while columns + the pose workgroup <= the number of compute units (ba_structure.cpp: upload) - a 512-thread
+// workgroup of this kernel always finds a CU, so every workgroup of the grid is resident and the order in which the hardware
+// dispatches them does not matter (HIP promises none).  Longer trajectories take the per-level launches.  A timeout (status
+// kBackSolveTimeout) is therefore a DEFECT, reported to the caller as SVI_ERR_INTERNAL and never folded into the LM rule.  A workgroup requests the
 // rows of L_kk^-1, its y_k and every L_ik row it will use right away - none of that depends on another column - and then
 // waits, entry by entry, for the x_i of the rows above: the forward phase left "pending" markers in the solution vector, a
 // marker that disappears IS the hand-over (one remote read per dependency level: 16 hops instead of 16 launches).  Every wait
 // is bounded: a value that never arrives (which would be a defect) ends the kernel with a status instead of hanging the GPU.
 // The trial poses, by one extra workgroup of k_back_solve_all: a lane per pose, waiting for that pose's six dx entries the way
 // the column workgroups wait for their x segments (bounded; a timeout or a failed factorisation ends the trial as failed).
-__device__ void pose_tail_wg(const PoseTail& pt, const double* x, int* status)
+__device__ void pose_tail_wg(const PoseTail& pt, const double* x, int* status, int kSpinLimit)
 {
-    constexpr int NW = kPotrfThreads / 64, kSpinLimit = 1 << 22;
+    constexpr int NW = kPotrfThreads / 64;
     __shared__ double s_red[NW];
     __shared__ int s_bad;
     if (threadIdx.x == 0) s_bad = 0;
@@ -1166,15 +1172,14 @@ __device__ void pose_tail_wg(const PoseTail& pt, const double* x, int* status)
 template <int TS>
 __global__ __launch_bounds__(kPotrfThreads) void k_back_solve_all(const SolveRec* __restrict__ recs, const double* __restrict__ Lt,
                                                                   const double* __restrict__ Linv, const double* __restrict__ y, double* x, int* status,
-                                                                  PoseTail pt)
+                                                                  PoseTail pt, int kSpinLimit)
 {
     static_assert(TS == 48, "written for the 48-wide tile (one column set per lane)");
     if (pt.src != nullptr && blockIdx.x == gridDim.x - 1) { // the extra workgroup: the trial poses
-        if (*status == 0) pose_tail_wg(pt, x, status);
+        if (*status == 0) pose_tail_wg(pt, x, status, kSpinLimit);
         return;
     }
     constexpr int NW = kPotrfThreads / 64, RB = 24, NRB = TS / RB, MAXU = (kInlineSub * NRB + NW - 1) / NW;
-    constexpr int kSpinLimit = 1 << 22;
     __shared__ double s_part[NW][TS];
     __shared__ double s_x[NW][RB];
     __shared__ double s_acc[TS];
@@ -1221,8 +1226,14 @@ __global__ __launch_bounds__(kPotrfThreads) void k_back_solve_all(const SolveRec
         if (wave + NW * s >= nq * NRB) break; // uniform
         double xin = 0.0;
         if (lane < RB) {
+            // bounded, and a waiter gives up at once when a column further up the chain has (its failure is in the status word:
+            // without this look every dependant would burn its whole budget, seconds, behind a hand-over that never comes)
             int spins = 0;
-            do { xin = __hip_atomic_load(xsrc[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while (is_solve_pending(xin) && ++spins < kSpinLimit);
+            do {
+                xin = __hip_atomic_load(xsrc[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (!is_solve_pending(xin)) break;
+                if ((spins & 255) == 255 && __hip_atomic_load(status, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) break;
+            } while (++spins < kSpinLimit);
             bad = bad || is_solve_pending(xin);
         }
         asm volatile("" ::: "memory");
@@ -1321,7 +1332,8 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
         if (one_launch) {
             PoseTail pt{};
             if (tail) { pt = *tail; if (tail_done) *tail_done = 1; }
-            hipLaunchKernelGGL(k_back_solve_all<TS>, dim3(p.n_solve_cols + (tail ? 1 : 0)), dim3(kPotrfThreads), 0, s, p.solve_recs, Lt, Linv, yv, x, status, pt);
+            hipLaunchKernelGGL(k_back_solve_all<TS>, dim3(p.n_solve_cols + (tail ? 1 : 0)), dim3(kPotrfThreads), 0, s, p.solve_recs, Lt, Linv, yv, x, status, pt,
+                               g_backsolve_spin_limit.load(std::memory_order_relaxed));
             return 0;
         }
     }

@@ -14,6 +14,7 @@
 #include "ba_host.h"
 
 #include <algorithm>
+#include <atomic>
 #include <cfloat>
 #include <chrono>
 #include <cmath>
@@ -47,6 +48,9 @@ void ba_configure_kernels(int TS);
 int chol_potrf_probe(int tile, int reps, int stop_after, double* ms);
 int chol_factor_solve(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n,
                       int* status, void* st, const PoseTail* tail, int* tail_done);
+// polls a workgroup of the one-launch backward substitution grants a pending entry before it gives up (ba_chol.hip reads it;
+// svi_debug_set_backsolve_spin_limit: the tests shrink it to provoke the time-out path)
+std::atomic<int> g_backsolve_spin_limit{1 << 22};
 int build_structure(svi_ba* ba); // ba_structure.cpp
 int reupload_state(svi_ba* ba);
 
@@ -70,11 +74,24 @@ void PhaseTimer::end(hipStream_t s)
 }
 void PhaseTimer::collect()
 {
+    // A record whose events have not completed yet (a sweep enqueued behind the numbers the host has just read may still be
+    // running) stays in the pool for the next collect - it is neither dropped nor waited for; records marked "discarded"
+    // (phase < 0: a speculated sweep whose trial was rejected or whose block ended) are skipped.
+    size_t keep = 0;
     for (size_t i = 0; i < used; ++i) {
+        if (pool[i].phase < 0) continue;
         float t = 0.f;
-        if (hipEventElapsedTime(&t, pool[i].a, pool[i].b) == hipSuccess) { ms[pool[i].phase] += t; calls[pool[i].phase]++; }
+        const hipError_t e = hipEventElapsedTime(&t, pool[i].a, pool[i].b);
+        if (e == hipSuccess) { ms[pool[i].phase] += t; calls[pool[i].phase]++; }
+        else if (e == hipErrorNotReady) { if (keep != i) std::swap(pool[keep], pool[i]); ++keep; }
+        else (void)hipGetLastError(); // (the record is lost; the error must not surface in an unrelated call)
     }
-    used = 0;
+    if (keep) (void)hipGetLastError(); // hipErrorNotReady is sticky in hipGetLastError
+    used = keep;
+}
+void PhaseTimer::drop_last()
+{
+    if (on && used > 0) pool[used - 1].phase = -1;
 }
 void PhaseTimer::release()
 {
@@ -279,6 +296,14 @@ int trial(svi_ba* ba, double lambda, bool* failed, bool speculate = false)
     // (evaluates the pose-only edges of the trial state itself)
     const bool spec = speculate && ba->opt.n_ranks == 1 && !t.on && !no_spec;
     SVI_TRY(reduce_and_read_trial(ba, 12, ba->cur ^ 1, spec ? (ba->cur ^ 1) : -1));
+    // -3: a hand-over of the one-launch backward substitution never arrived (ba_chol.hip).  That is a defect of the library, not
+    // a property of the matrix: it must not enter the LM rule as "not positive definite" (lambda would grow and the trajectory
+    // silently leave the reference's) - the call fails instead
+    if (ba->h_status[0] == -3) {
+        ba->stats.backsolve_timeouts++;
+        ba->spec_lin_state = -1;
+        return fail(SVI_ERR_INTERNAL, "backward substitution hand-over timed out (internal error; the estimates are unchanged)");
+    }
     // with several ranks the landmark blocks (and so the status word) are local: a failure anywhere arrives as a
     // non-finite chi2 through the all-reduce, so every rank takes the same branch of the LM rule
     *failed = ba->h_status[0] != 0 || (ba->opt.n_ranks > 1 && !std::isfinite(ba->h_scal[0]));
@@ -353,7 +378,11 @@ int optimize_block(svi_ba* ba, int iterations, int* performed)
         do {
             bool failed = false;
             // a rejected trial whose speculative successor sweep has overwritten this iteration's linearisation: once more
-            if (ba->spec_lin_state >= 0 && ba->spec_lin_state != ba->cur) { ba->spec_lin_state = -1; SVI_TRY(linearize(ba, false)); }
+            if (ba->spec_lin_state >= 0 && ba->spec_lin_state != ba->cur) {
+                ba->sweep_timer.drop_last(); // (that sweep linearised a state that was never accepted: not a linearisation of the LM loop)
+                ba->spec_lin_state = -1;
+                SVI_TRY(linearize(ba, false));
+            }
             SVI_TRY(trial(ba, ba->lambda, &failed, it + 1 < iterations));
             if (!have_lin) {
                 chi = ba->h_scal[8];
@@ -386,10 +415,12 @@ int optimize_block(svi_ba* ba, int iterations, int* performed)
         if (q == o.lm_max_trials || rho == 0 || stop_inf) break; // SolverResult::Terminate
     }
     if (performed) *performed = done;
+    // a sweep speculated behind the last trial of a block that then terminated is never used (the next block starts from -1)
+    if (ba->spec_lin_state >= 0) { ba->sweep_timer.drop_last(); ba->spec_lin_state = -1; }
     // the estimates stay on the device; the host copy is refreshed by the first call that reads it (ensure_host)
     ba->host_stale = true;
     ba->timer.collect();
-    // the last trial's scalars have been read: every sweep of this block has completed, its events can be queried
+    // the last trial's scalars have been read: the sweeps in front of them have completed (a record that has not stays pending)
     ba->sweep_timer.collect();
     return SVI_OK;
 }
@@ -723,6 +754,7 @@ int svi_ba_initialize(svi_ba* ba)
     ba->have_chi = false;
     ba->hinv_valid = false;          // (hand-overs between a linearisation and its trial: none is pending across an initialize)
     ba->lin_post_deferred = false;
+    ba->spec_lin_state = -1;         // (nor a speculated sweep: the estimates may have been edited)
     // every edit of the graph's structure clears `initialized`: if it is still set, the device structures are those of this very
     // graph and only the estimates have to go back (g2o rebuilds everything per call; the result is the same)
     if (ba->initialized) return reupload_state(ba);
@@ -1003,6 +1035,13 @@ int svi_ba_debug_aux_jacobians(svi_ba* ba, double* se3_err, double* se3_Ji, doub
     return SVI_OK;
 }
 
+int svi_debug_set_backsolve_spin_limit(int polls)
+{
+    if (polls < 1) return fail(SVI_ERR_INVALID, "spin limit must be >= 1");
+    g_backsolve_spin_limit.store(polls, std::memory_order_relaxed);
+    return SVI_OK;
+}
+
 int svi_debug_chol_probe(int device, int tile, int reps, int stop_after, double* ms)
 {
     if (!ms || reps < 1 || (tile != 48 && tile != 96)) return fail(SVI_ERR_INVALID, "bad probe argument");
@@ -1085,6 +1124,7 @@ int svi_ba_debug_reduced_system(svi_ba* ba, double lambda, double* S, double* g,
     const int64_t n = 6 * (int64_t)d.Pf;
     *n_out = n;
     if (cap < n) return fail(SVI_ERR_INVALID, "capacity %lld < n %lld", (long long)cap, (long long)n);
+    ba->spec_lin_state = -1; // (a block that ended on a rejected speculated trial leaves the buffers of ANOTHER state's sweep behind)
     SVI_TRY(linearize(ba));
     SVI_HIP(hipMemsetAsync(d.chol_status, 0, sizeof(int), ba->stream));
     ba_invert_landmarks(d, lambda, ba->stream);

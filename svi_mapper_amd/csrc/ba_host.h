@@ -43,7 +43,8 @@ struct PhaseTimer {
     bool on = false;
     void begin(int phase, hipStream_t s);
     void end(hipStream_t s);
-    void collect(); // after a stream sync
+    void collect();   // completed records are added up, pending ones kept
+    void drop_last(); // the record just closed does not count (a discarded speculative sweep)
     void release();
 };
 

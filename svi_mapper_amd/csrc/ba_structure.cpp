@@ -1092,7 +1092,11 @@ int upload(Build& b)
                     recs.push_back(r);
                 }
             p.solve_recs = nullptr; p.n_solve_cols = 0; p.ybuf = nullptr;
-            if (ok && !recs.empty() && recs.size() <= 1024) {
+            // every workgroup of that launch (a column each + the pose workgroup) must be resident at once: a workgroup spins on
+            // values other workgroups of the same launch publish, and HIP promises no dispatch order (ba_chol.hip)
+            int n_cu = device_compute_units(ba->opt.device);
+            if (n_cu <= 0) n_cu = 64;
+            if (ok && !recs.empty() && (int)recs.size() + 1 <= n_cu) {
                 SVI_TRY(up.up(recs, &p.solve_recs));
                 p.n_solve_cols = (int)recs.size();
                 double* yb = nullptr;
@@ -1141,7 +1145,7 @@ int reupload_state(svi_ba* ba)
     SVI_HIP(hipMemsetAsync(d.chol_status, 0, sizeof(int), ba->stream));
     SVI_HIP(hipMemsetAsync(d.aux_count, 0, sizeof(int), ba->stream));
     SVI_HIP(hipMemsetAsync(d.tr_count, 0, sizeof(int), ba->stream));
-    ba->hinv_valid = false; ba->lin_post_deferred = false;
+    ba->hinv_valid = false; ba->lin_post_deferred = false; ba->spec_lin_state = -1;
     ba->h_status[0] = ba->h_status[1] = 0;
     ba->pub_seq = 0;
     ba->lin_local = false;
@@ -1182,9 +1186,9 @@ int build_structure(svi_ba* ba)
     b.mark(8);
 
     svi_ba_stats& st = ba->stats;
-    const uint64_t it0 = st.lm_iterations, tr0 = st.lm_trials, cf0 = st.chol_failures;
+    const uint64_t it0 = st.lm_iterations, tr0 = st.lm_trials, cf0 = st.chol_failures, bt0 = st.backsolve_timeouts;
     st = svi_ba_stats{};
-    st.lm_iterations = it0; st.lm_trials = tr0; st.chol_failures = cf0;
+    st.lm_iterations = it0; st.lm_trials = tr0; st.chol_failures = cf0; st.backsolve_timeouts = bt0;
     st.n_poses = b.Pn; st.n_poses_free = b.Pf; st.n_landmarks = b.Ltot; st.n_landmarks_local = b.Ll;
     st.n_edges_proj = b.Etot; st.n_edges_proj_local = b.E;
     st.n_edges_se3 = (int64_t)ba->se3.size(); st.n_edges_accel = (int64_t)ba->acc.size(); st.n_edges_lmlm = (int64_t)ba->lmlm.size();

@@ -15,6 +15,7 @@ const char* svi_status_string(int status)
     case SVI_ERR_NOT_FOUND: return "vertex id not found";
     case SVI_ERR_IO: return "file i/o error";
     case SVI_ERR_COMM: return "all-reduce hook failed";
+    case SVI_ERR_INTERNAL: return "internal error";
     default: return "unknown status";
     }
 }

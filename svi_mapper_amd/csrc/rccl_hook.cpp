@@ -9,6 +9,7 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <string>
 
 #include "common.h"
@@ -29,26 +30,34 @@ struct Api {
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
 };
 
-Api* api()
+// loaded once, by whichever thread asks first (several shard threads of one process may initialise side by side: a function-local
+// static is initialised exactly once and the others wait for it); load_error keeps the loader's message for the callers
+std::string g_load_error;
+
+Api load_api()
 {
-    static Api a;
-    static bool tried = false;
-    if (tried) return a.lib ? &a : nullptr;
-    tried = true;
+    Api a;
     std::string rocm = getenv("ROCM_PATH") ? getenv("ROCM_PATH") : "/opt/rocm";
     const std::string cands[] = {"librccl.so", "librccl.so.1", rocm + "/lib/librccl.so"};
     for (const std::string& c : cands) {
         void* h = dlopen(c.c_str(), RTLD_NOW | RTLD_GLOBAL);
-        if (!h) continue;
+        if (!h) { const char* e = dlerror(); g_load_error = e ? e : "not found"; continue; } // (dlerror clears itself: read once)
         a.GetUniqueId = reinterpret_cast<decltype(a.GetUniqueId)>(dlsym(h, "ncclGetUniqueId"));
         a.CommInitRank = reinterpret_cast<decltype(a.CommInitRank)>(dlsym(h, "ncclCommInitRank"));
         a.CommDestroy = reinterpret_cast<decltype(a.CommDestroy)>(dlsym(h, "ncclCommDestroy"));
         a.AllReduce = reinterpret_cast<decltype(a.AllReduce)>(dlsym(h, "ncclAllReduce"));
         a.GetErrorString = reinterpret_cast<decltype(a.GetErrorString)>(dlsym(h, "ncclGetErrorString"));
-        if (a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString) { a.lib = h; return &a; }
+        if (a.GetUniqueId && a.CommInitRank && a.CommDestroy && a.AllReduce && a.GetErrorString) { a.lib = h; return a; }
+        g_load_error = c + ": an ncclXxx entry point is missing";
         dlclose(h);
     }
-    return nullptr;
+    return Api{};
+}
+
+Api* api()
+{
+    static Api a = load_api();
+    return a.lib ? &a : nullptr;
 }
 
 int nccl_fail(Api* a, const char* what, ncclResult_t r)
@@ -65,11 +74,16 @@ struct svi_rccl {
 
 extern "C" {
 
+// 1 if librccl resolved in this process (nothing collective happens here): the ranks exchange this answer BEFORE any of them
+// enters ncclCommInitRank, which blocks until every rank has arrived - a rank that cannot load the library must not leave the
+// others waiting inside it
+int svi_rccl_available(void) { return api() ? 1 : 0; }
+
 int svi_rccl_unique_id(void* id_out)
 {
     if (!id_out) return svi::fail(SVI_ERR_INVALID, "svi_rccl_unique_id: null argument");
     Api* a = api();
-    if (!a) return svi::fail(SVI_ERR_COMM, "librccl.so could not be loaded: %s", dlerror() ? dlerror() : "not found");
+    if (!a) return svi::fail(SVI_ERR_COMM, "librccl.so could not be loaded: %s", g_load_error.c_str());
     ncclUniqueId id;
     const ncclResult_t r = a->GetUniqueId(&id);
     if (r != 0) return nccl_fail(a, "ncclGetUniqueId", r);
@@ -83,7 +97,7 @@ int svi_rccl_create(const void* unique_id, int rank, int n_ranks, int device, sv
     *out = nullptr;
     if (n_ranks < 1 || rank < 0 || rank >= n_ranks) return svi::fail(SVI_ERR_INVALID, "svi_rccl_create: bad rank %d / n_ranks %d", rank, n_ranks);
     Api* a = api();
-    if (!a) return svi::fail(SVI_ERR_COMM, "librccl.so could not be loaded");
+    if (!a) return svi::fail(SVI_ERR_COMM, "librccl.so could not be loaded: %s", g_load_error.c_str());
     if (int rc = svi::use_device(device)) return rc;
     ncclUniqueId id;
     memcpy(&id, unique_id, sizeof(id));

@@ -72,26 +72,38 @@ class NativeRccl:
     id of rank 0 reaches the other ranks through `exchange(id_bytes_or_None) -> id_bytes` (here: torch.distributed's object
     broadcast, any side channel will do); after that no Python sits between the library and RCCL."""
 
-    def __init__(self, rank, n_ranks, device, exchange=None):
+    def __init__(self, rank, n_ranks, device, exchange=None, agree=None):
+        """agree(ok) -> bool (optional with a custom `exchange`): True iff EVERY rank passed ok=True.  ncclCommInitRank blocks
+        until all ranks have entered it, so the ranks first agree that librccl resolved on every one of them (and that rank 0
+        got its unique id); if not, all of them raise here - none is left waiting inside the collective initialisation - and
+        the caller falls back (bench.py: the torch.distributed hook) on every rank alike."""
         import ctypes as C
 
         from . import _capi
         lib = _capi.load_library()
         buf = (C.c_char * 128)()
-        failed = None
-        if rank == 0 and lib.svi_rccl_unique_id(buf) != 0:
+        ok = lib.svi_rccl_available() == 1
+        failed = None if ok else "librccl.so could not be loaded on rank %d" % rank
+        if ok and rank == 0 and lib.svi_rccl_unique_id(buf) != 0:
             failed = lib.svi_last_error().decode()   # (reported AFTER the exchange: the other ranks are waiting in it)
         raw = bytes(buf)
         if n_ranks > 1:
             if exchange is None:
                 import torch.distributed as dist
-                box = [(None if failed else raw) if rank == 0 else None]
+                votes = [None] * n_ranks
+                dist.all_gather_object(votes, failed)
+                bad = [v for v in votes if v]
+                if bad:
+                    raise RuntimeError("native RCCL hook unavailable: %s" % "; ".join(bad))
+                box = [raw if rank == 0 else None]
                 dist.broadcast_object_list(box, src=0)
                 raw = box[0]
             else:
+                if agree is not None and not agree(failed is None):
+                    raise RuntimeError("native RCCL hook unavailable: %s" % (failed or "another rank could not load librccl"))
                 raw = exchange((None if failed else raw) if rank == 0 else None)
         if failed or raw is None:
-            raise RuntimeError("svi_rccl_unique_id failed on rank 0: %s" % (failed or "see rank 0"))
+            raise RuntimeError("svi_rccl setup failed: %s" % (failed or "see rank 0"))
         idb = (C.c_char * 128).from_buffer_copy(raw)
         h = C.c_void_p()
         _capi.check(lib.svi_rccl_create(idb, int(rank), int(n_ranks), int(device), C.byref(h)), "svi_rccl_create")

@@ -351,6 +351,107 @@ def test_c3_first_block_parity(svi, oracle):
     assert abs(g.last_plain_chi2 - o.last_plain_chi2) <= 1e-6 * o.last_plain_chi2
 
 
+def _assert_full_schedule_parity(r):
+    """north_star: the same LM iteration count, poses / landmarks within 1e-4 relative, plain chi2 within 1e-6."""
+    ng, eg, no, eo = r["iters"]
+    assert (ng, eg) == (no, eo), "nominal / executed LM iterations: product %s, oracle %s" % ((ng, eg), (no, eo))
+    Tg, To = r["T"]
+    pg, po = r["p"]
+    assert _rel(Tg[:, 9:], To[:, 9:]) < REL
+    assert np.abs(Tg[:, :9] - To[:, :9]).max() < REL
+    assert _rel(pg, po) < REL
+    cg, co = r["g"].last_plain_chi2, r["o"].last_plain_chi2
+    assert abs(cg - co) <= 1e-6 * co
+    st = r["g"].stats()
+    assert st.chol_failures == 0 and st.lm_iterations == eg
+
+
+def test_c3_full_schedule_parity(svi, oracle):
+    """BASELINE config 3, the WHOLE _optimizeUnLimited schedule (Cg2oOptimizer.cpp:954-980: optimize(1), then blocks of
+    optimize(10) while the plain chi2 improves by more than 1 %): 51 LM iterations in product and oracle alike."""
+    r = _full_schedule(svi, oracle, synth.make_c3())
+    _assert_full_schedule_parity(r)
+    assert r["iters"][1] >= 11  # more than the first block: the ratio test of :969 has been taken at least once
+
+
+def test_c4_full_schedule_parity(svi, oracle):
+    """BASELINE config 4 at full size (500 KF / 100 k landmarks / 800 k edges), the whole schedule: 61 LM iterations. The
+    oracle's full-system sparse LL' needs about half a second per iteration on one host core, so this is the longest test
+    of the suite (about a minute)."""
+    r = _full_schedule(svi, oracle, synth.make_c4())
+    _assert_full_schedule_parity(r)
+    assert r["iters"][1] >= 21
+
+
+def test_reduced_system_after_a_block_that_ended_on_a_rejected_trial(svi):
+    """(round-2 advisor finding) With lm_max_trials = 1 a rejected first trial ends the block while the sweep that was
+    speculated behind it - the linearisation of the REJECTED state - sits in the linearisation buffers.  The next
+    linearisation outside optimize() (the reduced-system tap) must not mistake it for its own: after initialize() the tap has
+    to return the system of the untouched initial estimate, bit for bit what a fresh handle returns."""
+    import functools
+    found = 0
+    for rot, seed in [(0.3, 3), (0.35, 6), (0.35, 8), (0.4, 2), (0.4, 5), (0.45, 9)]:
+        ref = _nonlinear_graph(svi.BundleAdjuster, 1e-12, rot, seed=seed)
+        ref.initialize()
+        S0, g0 = ref.reduced_system(0.25)
+        g = _nonlinear_graph(functools.partial(svi.BundleAdjuster, lm_max_trials=1), 1e-12, rot, seed=seed)
+        g.initialize()
+        T0 = g.get_poses()[1].copy()
+        done = g.optimize(3)
+        st = g.stats()
+        if not (done == 1 and st.lm_trials == 1 and np.array_equal(g.get_poses()[1], T0)):
+            continue  # the first trial was accepted: not the case under test
+        found += 1
+        g.initialize()
+        S1, g1 = g.reduced_system(0.25)
+        assert np.array_equal(S0, S1) and np.array_equal(g0, g1)
+        assert g.optimize(1) == 1  # and the handle goes on working
+    assert found > 0, "none of the graphs had its first trial rejected"
+
+
+def test_backsolve_timeout_is_an_internal_error(svi):
+    """A hand-over of the one-launch backward substitution that never arrives is a defect, not a property of the matrix:
+    svi_ba_optimize returns SVI_ERR_INTERNAL (9), the trial is not counted as a failed factorisation, lambda does not
+    grow, and with the spin budget restored the same handle produces what a fresh handle does."""
+    from svi_mapper_amd import _capi
+    lib = _capi.load_library()
+    prob = synth.make_ba_problem(100, 3000, 20000, seed=77)
+    ref, _ = _make(svi.BundleAdjuster, prob)
+    ref.initialize()
+    assert ref.stats().chol_steps >= 3
+    assert ref.optimize(3) == 3
+    g, _ = _make(svi.BundleAdjuster, prob)
+    g.initialize()
+    try:
+        assert lib.svi_debug_set_backsolve_spin_limit(1) == 0
+        with pytest.raises(svi.SviError) as e:
+            g.optimize(3)
+        assert e.value.status == 9
+    finally:
+        assert lib.svi_debug_set_backsolve_spin_limit(1 << 22) == 0
+    st = g.stats()
+    assert st.chol_failures == 0 and st.backsolve_timeouts == 1 and st.lm_iterations == 0
+    assert g.optimize(3) == 3
+    assert np.array_equal(g.get_poses()[1], ref.get_poses()[1]) and g.lm_lambda == ref.lm_lambda
+
+
+def test_long_trajectory_takes_the_per_level_backward_substitution(svi, oracle):
+    """2100 key frames = 263 tile columns: more than the one-launch backward substitution may hold resident (one workgroup per
+    column, bounded by the number of compute units), so the per-level launches run - against the oracle."""
+    prob = synth.make_ba_problem(2100, 6000, 30000, seed=0x2100)
+    g, _ = _make(svi.BundleAdjuster, prob)
+    o, _ = _make(oracle.OracleBA, prob)
+    g.initialize()
+    o.initialize()
+    assert g.stats().chol_n // 48 > 256
+    for n in (1, 2):
+        assert g.optimize(n) == o.optimize(n)
+    Tg, To = g.get_poses()[1], o.get_poses()[1]
+    pg, po = g.get_landmarks()[1], o.get_landmarks()[1]
+    assert _rel(Tg[:, 9:], To[:, 9:]) < REL and np.abs(Tg[:, :9] - To[:, :9]).max() < REL and _rel(pg, po) < REL
+    assert abs(g.last_plain_chi2 - o.last_plain_chi2) <= 1e-6 * o.last_plain_chi2
+
+
 def test_fixed_and_closure_edges(svi, oracle, small):
     """Landmark-closure EdgePointXYZ with a fixed partner (Cg2oOptimizer.cpp:445-458) and a fixed landmark."""
     def build(cls):

@@ -72,7 +72,7 @@ def _run_sharded(svi, prob, n_ranks, iters, extra=None, make=None):
     return out
 
 
-@pytest.mark.parametrize("n_ranks", [2, 3])
+@pytest.mark.parametrize("n_ranks", [2, 3, 8])
 def test_sharded_equals_unsharded(svi, n_ranks):
     prob = synth.make_ba_problem(30, 2000, 15000, seed=21)
     cam = prob["cam"]
@@ -113,6 +113,52 @@ def test_c4_two_shards_equal_unsharded(svi):
         assert np.abs(o[1] - T).max() < 1e-9 and np.abs(o[2] - p).max() < 1e-9 * np.abs(p).max()
         assert abs(o[3][0] - chi[0]) <= 1e-9 * chi[0]
     assert np.array_equal(out[0][1], out[1][1])
+
+
+def test_c4_eight_shards_equal_unsharded(svi):
+    """BASELINE config 4 as the target machine cuts it: EIGHT landmark shards (here on one GPU, one thread per rank). Rank 0
+    alone holds the pose-only edges, lambda_0 is exchanged at the first iteration of each block, the later iterations keep
+    their pose sums local: the same LM iterations / trials on every rank, bit-identical poses between the ranks, and the
+    estimates of the unsharded solve."""
+    prob = synth.make_c4()
+    cam = prob["cam"]
+    iters = (1, 3)
+    ref = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"])
+    synth.build_ba_graph(ref, prob)
+    ref.initialize()
+    done = [ref.optimize(n) for n in iters]
+    T, p = ref.get_poses()[1], ref.get_landmarks()[1]
+    chi = ref.chi2()
+    st = ref.stats()
+    ref.close()
+    out = _run_sharded(svi, prob, 8, iters)
+    loc = [o[4] for o in out]
+    assert sum(loc) == prob["n_lm"] and min(loc) > 0 and max(loc) < 1.6 * min(loc)   # (shards are balanced by EDGE count, not landmarks)
+    for o in out:
+        assert o[0] == done and o[5] == st.lm_trials and o[6] == 0
+        assert o[7] == out[0][7]                                  # the same damping on every rank, bit for bit
+        assert np.array_equal(o[1], out[0][1])
+        assert np.abs(o[1] - T).max() < 1e-9 and np.abs(o[2] - p).max() < 1e-9 * np.abs(p).max()
+        assert abs(o[3][0] - chi[0]) <= 1e-9 * chi[0]
+
+
+def test_more_ranks_than_work(svi):
+    """Eight ranks on a graph whose landmarks do not fill them evenly: shards are cut by edge count, so a rank may own very few
+    landmarks or none at all - it still takes part in every collective and ends with the same estimates."""
+    prob = synth.make_ba_problem(8, 12, 60, seed=11)
+    cam = prob["cam"]
+    iters = (1, 4)
+    ref = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"])
+    synth.build_ba_graph(ref, prob)
+    ref.initialize()
+    done = [ref.optimize(n) for n in iters]
+    T, p = ref.get_poses()[1], ref.get_landmarks()[1]
+    out = _run_sharded(svi, prob, 8, iters)
+    assert sum(o[4] for o in out) == prob["n_lm"]
+    for o in out:
+        assert o[0] == done
+        assert np.abs(o[1] - T).max() < 1e-9 and np.abs(o[2] - p).max() < 1e-9 * max(1.0, np.abs(p).max())
+        assert np.array_equal(o[1], out[0][1])
 
 
 def test_failed_trial_is_failed_on_every_rank(svi):
