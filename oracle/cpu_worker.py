@@ -12,7 +12,7 @@ import time
 import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-sys.path.insert(0, ROOT)
+sys.path[0] = ROOT   # (the script's own directory would shadow the package `oracle` with the module oracle/oracle.py)
 
 
 def main():

@@ -1276,9 +1276,10 @@ __global__ __launch_bounds__(kPotrfThreads) void k_back_solve_all(const SolveRec
     }
 }
 
+// levels [st_begin, st_end) of the factorisation, then (solve) the backward substitution
 template <int TS>
 int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n, int* status, hipStream_t s,
-        const PoseTail* tail, int* tail_done)
+        const PoseTail* tail, int* tail_done, int st_begin, int st_end, bool solve)
 {
     if (tail_done) *tail_done = 0;
     // one-launch backward substitution (tile 48, every column's list short enough): the forward vector then lives in p.ybuf and
@@ -1301,7 +1302,7 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
     sa.diag_tile = p.diag_tile; sa.pre_ptr = p.pre_ptr; sa.pre_tile = p.pre_tile; sa.pre_col = p.pre_col;
     sa.tgt_pair_ptr = p.tgt_pair_ptr; // indexed through the level's offset below
     sa.pair_a = p.pair_a; sa.pair_b = p.pair_b; sa.pair_src = p.pair_src;
-    for (int st = 0; st < p.n_steps; ++st) {
+    for (int st = st_begin; st < st_end; ++st) {
         const int c0 = p.h_step_ptr[st], nc = p.h_step_ptr[st + 1] - c0;
         const int t0 = p.h_tgt_ptr[st], ntg = p.h_tgt_ptr[st + 1] - t0;
         sa.n_chain = nc; sa.last_level = st == p.n_steps - 1; sa.chain_col = p.step_col + c0; sa.chain_desc = reinterpret_cast<const int4*>(p.step_desc) + 2 * c0;
@@ -1328,6 +1329,7 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
         }
     }
 #endif
+    if (!solve) return 0;
     if constexpr (TS == 48) {
         if (one_launch) {
             PoseTail pt{};
@@ -1406,8 +1408,17 @@ int chol_factor_solve(const CholPlan& p, double* S, double* Lt, double* Linv, do
                       void* st, const PoseTail* tail, int* tail_done)
 {
     hipStream_t s = static_cast<hipStream_t>(st);
-    return p.TS == 48 ? run<48>(p, S, Lt, Linv, g, x, lambda, n, status, s, tail, tail_done)
-                      : run<96>(p, S, Lt, Linv, g, x, lambda, n, status, s, tail, tail_done);
+    return p.TS == 48 ? run<48>(p, S, Lt, Linv, g, x, lambda, n, status, s, tail, tail_done, 0, p.n_steps, true)
+                      : run<96>(p, S, Lt, Linv, g, x, lambda, n, status, s, tail, tail_done, 0, p.n_steps, true);
+}
+
+// the same in pieces: levels [st_begin, st_end) only; the backward substitution (and the trial poses) behind the last piece
+int chol_factor_range(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n, int* status,
+                      void* st, const PoseTail* tail, int* tail_done, int st_begin, int st_end, int solve)
+{
+    hipStream_t s = static_cast<hipStream_t>(st);
+    return p.TS == 48 ? run<48>(p, S, Lt, Linv, g, x, lambda, n, status, s, tail, tail_done, st_begin, st_end, solve != 0)
+                      : run<96>(p, S, Lt, Linv, g, x, lambda, n, status, s, tail, tail_done, st_begin, st_end, solve != 0);
 }
 
 } // namespace svi

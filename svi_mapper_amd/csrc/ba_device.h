@@ -110,15 +110,17 @@ struct BaDev {
 
     // Schur reduction: cells of 4 x 4 poses (four per stored 48 x 48 sub-tile: cell = 4 sub + 2 u + v), items
     // (landmark x cell), quarter jobs (runs of items of one cell, 16 lanes), wavefront jobs (4 quarter jobs), slabs
-    int n_items, n_jobs, n_sub;
+    int n_items, n_jobs, n_sub; // n_jobs: wavefront jobs PER STAGE = 4 x the workgroups of k_schur; job slot = stage * n_jobs + job
+    int n_stages;               // stages of the Schur reduction (by dependency level of a tile's column, ba_structure.cpp); 1 = unstaged
+    int* stage_count;           // [n_stages] arrival counters of k_schur's waves (zero between launches)
     const int* it_pack;      // [n_items][4]: landmark, first edge of the row segment, first edge of the column segment, maskI | maskJ << 8
-    const int* qj_begin;     // [4 n_jobs] first item of quarter job 4 job + quarter
-    const int* qj_end;       // [4 n_jobs]
-    const int* qj_diag;      // [4 n_jobs] 1: diagonal cell (lower blocks only, carries g)
-    const int* job_merged;   // [n_jobs] 1: the four quarter jobs are pieces of one cell - the wave adds them up, quarter 0 carries the sum
-    const int* job_len;      // [n_jobs] longest of the four quarter jobs
-    double* slab;            // [n_jobs][36][64]  element q of the 6x6 block of lane (quarter = lane>>4, i = (lane>>2)&3, j = lane&3)
-    double* gslab;           // [4 n_jobs][6][4]
+    const int* qj_begin;     // [n_stages][4 n_jobs] first item of quarter job 4 job + quarter
+    const int* qj_end;       // [n_stages][4 n_jobs]
+    const int* qj_diag;      // [n_stages][4 n_jobs] 1: diagonal cell (lower blocks only, carries g)
+    const int* job_merged;   // [n_stages][n_jobs] 1: the four quarter jobs are pieces of one cell - the wave adds them up, quarter 0 carries the sum
+    const int* job_len;      // [n_stages][n_jobs] longest of the four quarter jobs
+    double* slab;            // [n_stages][n_jobs][36][64]  element q of the 6x6 block of lane (quarter = lane>>4, i = (lane>>2)&3, j = lane&3)
+    double* gslab;           // [n_stages][4 n_jobs][6][4]
     const int* cell_qj_ptr;  // [4 n_sub + 1] quarter jobs of a cell, in summation order
     const int* cell_qj;
     const int* sub_cx;       // [n_sub] sub-tile row / column in units of 48
@@ -162,6 +164,11 @@ struct PoseTail {
     int Pn, lin_from_red;
     double wl, wb;
 };
+
+// what a wave of k_schur does when it leaves a stage: the last wave to arrive publishes `seq` at sig[stage] (memory a stream
+// waits on with hipStreamWaitValue64; nullptr: nobody waits)
+constexpr int kMaxStages = 8;
+struct StageSignals { unsigned long long* sig[kMaxStages]; unsigned long long seq; };
 
 struct CholPlan {
     int TS = 0, NT = 0, n_steps = 0;

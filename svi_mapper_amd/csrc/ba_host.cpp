@@ -36,8 +36,8 @@ void ba_pose_finalize(const BaDev& d, const int* red_slot, int rank, int n_ranks
 void ba_publish(const BaDev& d, int n, double* h_scal, int* h_status, int seq, void* st);
 void ba_lin_post(const BaDev& d, int n_ranks, void* st);
 void ba_invert_landmarks(const BaDev& d, double lambda, void* st);
-void ba_schur(const BaDev& d, void* st);
-void ba_assemble(const BaDev& d, void* st);
+void ba_schur(const BaDev& d, const StageSignals* sg, void* st);
+void ba_assemble(const BaDev& d, int sub0, int sub1, int accumulate, void* st);
 void ba_update_poses(const BaDev& d, int cur, double lambda, int scale_mode, int rank, void* st);
 void ba_backsub_chi2(const BaDev& d, int cur, double lambda, void* st);
 void ba_chi2_only(const BaDev& d, int which, void* st);
@@ -51,6 +51,8 @@ int chol_factor_solve(const CholPlan& p, double* S, double* Lt, double* Linv, do
 // polls a workgroup of the one-launch backward substitution grants a pending entry before it gives up (ba_chol.hip reads it;
 // svi_debug_set_backsolve_spin_limit: the tests shrink it to provoke the time-out path)
 std::atomic<int> g_backsolve_spin_limit{1 << 22};
+int chol_factor_range(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n, int* status,
+                      void* st, const PoseTail* tail, int* tail_done, int st_begin, int st_end, int solve);
 int build_structure(svi_ba* ba); // ba_structure.cpp
 int reupload_state(svi_ba* ba);
 
@@ -147,12 +149,24 @@ int allreduce(svi_ba* ba, double* buf, size_t count)
 int wait_published(svi_ba* ba, int seq)
 {
     volatile int* flag = ba->h_status + 1;
+    const auto t0 = std::chrono::steady_clock::now();
     for (long spin = 0;; ++spin) {
         if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break;
         if ((spin & 0xFFF) == 0xFFF) { // every few thousand polls: has the stream died or drained without publishing?
             const hipError_t q = hipStreamQuery(ba->stream);
             if (q == hipSuccess) { if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) break; SVI_HIP(hipStreamSynchronize(ba->stream)); if (*flag == seq) break; return fail(SVI_ERR_HIP, "result publication lost"); }
             if (q != hipErrorNotReady) return fail(SVI_ERR_HIP, "stream failed while waiting for the trial results: %s", hipGetErrorString(q));
+            // A stream wait on a memory value has no time-out of its own.  If a stage of the Schur reduction were never published
+            // (a defect), the main stream would sit in its wait for ever: after 30 s the host publishes the values itself - the queue
+            // drains (with a wrong reduced system, which is discarded with the error) - and the handle stops using the second stream.
+            if (ba->overlap_ok && ba->stage_seq > 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(30)) {
+                for (int k = 0; k < kMaxStages; ++k) __atomic_store_n(ba->sig_stage[k], ~0ull >> 1, __ATOMIC_RELEASE);
+                __atomic_store_n(ba->sig_lin, ~0ull >> 1, __ATOMIC_RELEASE);
+                ba->overlap_ok = false;
+                (void)hipStreamSynchronize(ba->stream);
+                (void)hipStreamSynchronize(ba->stream_schur);
+                return fail(SVI_ERR_INTERNAL, "a stage of the Schur reduction was never published (stream wait released by the host after 30 s)");
+            }
         }
         __builtin_ia32_pause();
     }
@@ -253,12 +267,31 @@ int linearize(svi_ba* ba, bool read = true)
 // one trial: solve (H + lambda I) dx = b through the Schur complement, apply, evaluate.
 // results: h_scal[0] robust chi2, [1] plain chi2, [2]+[3] step scale; *failed
 // k_assemble with the pose terms matching what linearize() left in Hpp / bp: totals (rank 0 adds them) or this rank's share
-void assemble(svi_ba* ba)
+// stage < 0: every sub-tile.  With several stages the tiles and g start a trial as zeros (zero_reduced_system) and everything
+// that reaches them - the assembled blocks of their stage, the updates of the factorisation's levels - is added.
+void assemble(svi_ba* ba, int stage = -1)
 {
     BaDev& d = ba->d;
     d.add_pose_terms = (ba->lin_local || ba->opt.rank == 0) ? 1 : 0;
     d.lin_from_red = ba->lin_local ? 1 : 0;
-    ba_assemble(d, ba->stream);
+    const int acc = d.n_stages > 1 ? 1 : 0;
+    if (stage < 0) ba_assemble(d, 0, d.n_sub, acc, ba->stream);
+    else ba_assemble(d, ba->sub_stage_ptr[stage], ba->sub_stage_ptr[stage + 1], acc, ba->stream);
+}
+
+int zero_reduced_system(svi_ba* ba)
+{
+    BaDev& d = ba->d;
+    if (d.n_stages > 1 && d.NT > 0)
+        SVI_HIP(hipMemsetAsync(d.g, 0, sizeof(double) * ((size_t)d.NT * d.TS + (size_t)d.n_tiles * d.TS * d.TS), ba->stream));
+    return SVI_OK;
+}
+
+// the Schur reduction of a trial on its own stream, the factorisation level by level behind the stages it finishes
+bool use_overlap(const svi_ba* ba)
+{
+    static const bool off = getenv("SVI_NO_OVERLAP") != nullptr;
+    return ba->overlap_ok && !off && ba->d.n_stages > 1 && ba->opt.n_ranks == 1 && !ba->timer.on;
 }
 
 int trial(svi_ba* ba, double lambda, bool* failed, bool speculate = false)
@@ -267,15 +300,6 @@ int trial(svi_ba* ba, double lambda, bool* failed, bool speculate = false)
     hipStream_t s = ba->stream;
     PhaseTimer& t = ba->timer;
     // (the status word is clean: whoever read it last cleared it)
-    t.begin(SVI_PH_SCHUR, s);
-    if (!(ba->hinv_valid && ba->hinv_lambda == lambda)) ba_invert_landmarks(d, lambda, s);
-    ba->hinv_valid = false; // (a second trial of the iteration comes with another lambda)
-    ba_schur(d, s);
-    t.end(s);
-    t.begin(SVI_PH_ASSEMBLE, s); assemble(ba); t.end(s);
-    SVI_HIP(hipGetLastError());
-    SVI_TRY(allreduce(ba, ba->lin_local ? d.red_base : d.g, (size_t)d.red_count + (ba->lin_local ? 2 : 0)));
-    t.begin(SVI_PH_CHOLESKY, s);
     // the trial poses ride in the last launch of the solve (an extra workgroup that waits for its dx entries): a launch of their
     // own was 5 us + a boundary between the backward substitution and the landmark back-substitution (not while phases are timed)
     const int scale_mode = ba->opt.n_ranks <= 1 ? 0 : (ba->lin_local ? 2 : 1);
@@ -286,9 +310,48 @@ int trial(svi_ba* ba, double lambda, bool* failed, bool speculate = false)
     int tail_done = 0;
     static const bool no_tail = getenv("SVI_NO_POSE_TAIL") != nullptr; // (A/B timing)
     static const bool no_spec = getenv("SVI_NO_SPECULATION") != nullptr;
-    if (d.NT > 0 && chol_factor_solve(ba->plan, d.S, d.Lt, d.Linv, d.g, d.dx, lambda, 6 * d.Pf, d.chol_status, s, (t.on || no_tail) ? nullptr : &tail, &tail_done) != 0)
-        return fail(SVI_ERR_HIP, "Cholesky kernels could not be configured (LDS request refused)");
-    t.end(s);
+    const PoseTail* tailp = (t.on || no_tail) ? nullptr : &tail;
+    SVI_TRY(zero_reduced_system(ba));
+    t.begin(SVI_PH_SCHUR, s);
+    if (!(ba->hinv_valid && ba->hinv_lambda == lambda)) ba_invert_landmarks(d, lambda, s);
+    ba->hinv_valid = false; // (a second trial of the iteration comes with another lambda)
+    if (use_overlap(ba) && d.NT > 0) {
+        // main stream: "linearisation ready" -> Schur stream: k_schur, stage by stage -> main stream: per stage, assemble its
+        // sub-tiles and factorise the dependency levels whose columns it holds.  Only the first stage's wait is on the critical
+        // path: from then on the factorisation (17 launches, ~15 us each at config 4) is what the reduction has to keep ahead of.
+        const unsigned long long seq = ++ba->stage_seq;
+        StageSignals sg{};
+        for (int k = 0; k < d.n_stages; ++k) sg.sig[k] = ba->sig_stage[k];
+        sg.seq = seq;
+        SVI_HIP(hipStreamWriteValue64(s, ba->sig_lin, seq, 0));
+        SVI_HIP(hipStreamWaitValue64(ba->stream_schur, ba->sig_lin, seq, hipStreamWaitValueGte, ~0ull));
+        ba_schur(d, &sg, ba->stream_schur);
+        SVI_HIP(hipGetLastError());
+        const int n_steps = ba->plan.n_steps;
+        int st = 0;
+        for (int stage = 0; stage < d.n_stages; ++stage) {
+            SVI_HIP(hipStreamWaitValue64(s, ba->sig_stage[stage], seq, hipStreamWaitValueGte, ~0ull));
+            assemble(ba, stage);
+            int st1 = st;
+            while (st1 < n_steps && ba->level_stage[st1] == stage) ++st1;
+            const bool last = stage == d.n_stages - 1;
+            if (last) st1 = n_steps;
+            if (chol_factor_range(ba->plan, d.S, d.Lt, d.Linv, d.g, d.dx, lambda, 6 * d.Pf, d.chol_status, s, tailp, &tail_done, st, st1, last ? 1 : 0) != 0)
+                return fail(SVI_ERR_HIP, "Cholesky kernels could not be configured (LDS request refused)");
+            st = st1;
+        }
+        SVI_HIP(hipGetLastError());
+    } else {
+        ba_schur(d, nullptr, s);
+        t.end(s);
+        t.begin(SVI_PH_ASSEMBLE, s); assemble(ba); t.end(s);
+        SVI_HIP(hipGetLastError());
+        SVI_TRY(allreduce(ba, ba->lin_local ? d.red_base : d.g, (size_t)d.red_count + (ba->lin_local ? 2 : 0)));
+        t.begin(SVI_PH_CHOLESKY, s);
+        if (d.NT > 0 && chol_factor_solve(ba->plan, d.S, d.Lt, d.Linv, d.g, d.dx, lambda, 6 * d.Pf, d.chol_status, s, tailp, &tail_done) != 0)
+            return fail(SVI_ERR_HIP, "Cholesky kernels could not be configured (LDS request refused)");
+        t.end(s);
+    }
     t.begin(SVI_PH_BACKSUB_UPDATE, s);
     if (!tail_done) ba_update_poses(d, ba->cur, lambda, scale_mode, ba->opt.rank, s);
     ba_backsub_chi2(d, ba->cur, lambda, s);
@@ -533,12 +596,27 @@ int svi_ba_create(const svi_ba_options* o, svi_ba** out)
     if (ba->opt.chol_tile == 0) ba->opt.chol_tile = 48;
     if (o->stream) ba->stream = static_cast<hipStream_t>(o->stream);
     else {
-        hipError_t e = hipStreamCreateWithFlags(&ba->stream, hipStreamNonBlocking);
+        // (the highest priority there is: the factorisation's short launches run on this stream beside the Schur stream's one long kernel)
+        int lo = 0, hi = 0;
+        hipError_t e = hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess ? hipStreamCreateWithPriority(&ba->stream, hipStreamNonBlocking, hi)
+                                                                                 : hipStreamCreateWithFlags(&ba->stream, hipStreamNonBlocking);
         if (e != hipSuccess) { delete ba; return fail(SVI_ERR_HIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
         ba->own_stream = true;
     }
     ba->timer.on = o->profile != 0;
     ba->sweep_timer.on = o->sweep_events != 0 && o->profile == 0;
+    {   // the second stream and the memory values that tie it to the first (see ba_host.h); without them trials run on one stream
+        int can = 0;
+        bool ok = hipDeviceGetAttribute(&can, hipDeviceAttributeCanUseStreamWaitValue, ba->opt.device) == hipSuccess && can != 0;
+        ok = ok && hipStreamCreateWithFlags(&ba->stream_schur, hipStreamNonBlocking) == hipSuccess;
+        ok = ok && hipExtMallocWithFlags(reinterpret_cast<void**>(&ba->sig_lin), 8, hipMallocSignalMemory) == hipSuccess;
+        for (int k = 0; k < kMaxStages && ok; ++k) ok = hipExtMallocWithFlags(reinterpret_cast<void**>(&ba->sig_stage[k]), 8, hipMallocSignalMemory) == hipSuccess;
+        if (ok) {
+            *ba->sig_lin = 0;
+            for (int k = 0; k < kMaxStages; ++k) *ba->sig_stage[k] = 0;
+        } else (void)hipGetLastError();
+        ba->overlap_ok = ok;
+    }
     *out = ba;
     return SVI_OK;
 }
@@ -548,6 +626,9 @@ int svi_ba_destroy(svi_ba* ba)
     if (!ba) return SVI_OK;
     (void)hipSetDevice(ba->opt.device);
     (void)hipStreamSynchronize(ba->stream);
+    if (ba->stream_schur) { (void)hipStreamSynchronize(ba->stream_schur); (void)hipStreamDestroy(ba->stream_schur); ba->stream_schur = nullptr; }
+    if (ba->sig_lin) { (void)hipFree(ba->sig_lin); ba->sig_lin = nullptr; }
+    for (int k = 0; k < kMaxStages; ++k) if (ba->sig_stage[k]) { (void)hipFree(ba->sig_stage[k]); ba->sig_stage[k] = nullptr; }
     free_device(ba);
     if (ba->proj.vals) { (void)hipHostFree(ba->proj.vals); ba->proj.vals = nullptr; }
     ba->timer.release();
@@ -750,6 +831,7 @@ int svi_ba_initialize(svi_ba* ba)
     SVI_TRY(ensure_host(ba));
     if (int rc = use_device(ba->opt.device)) return rc;
     SVI_HIP(hipStreamSynchronize(ba->stream)); // nothing may still read the buffers that are about to be refilled
+    if (ba->stream_schur) SVI_HIP(hipStreamSynchronize(ba->stream_schur));
     ba->cur = 0;
     ba->have_chi = false;
     ba->hinv_valid = false;          // (hand-overs between a linearisation and its trial: none is pending across an initialize)
@@ -1127,8 +1209,9 @@ int svi_ba_debug_reduced_system(svi_ba* ba, double lambda, double* S, double* g,
     ba->spec_lin_state = -1; // (a block that ended on a rejected speculated trial leaves the buffers of ANOTHER state's sweep behind)
     SVI_TRY(linearize(ba));
     SVI_HIP(hipMemsetAsync(d.chol_status, 0, sizeof(int), ba->stream));
+    SVI_TRY(zero_reduced_system(ba));
     ba_invert_landmarks(d, lambda, ba->stream);
-    ba_schur(d, ba->stream);
+    ba_schur(d, nullptr, ba->stream);
     assemble(ba);
     SVI_HIP(hipGetLastError());
     SVI_TRY(allreduce(ba, d.g, (size_t)d.red_count));

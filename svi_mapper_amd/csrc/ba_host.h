@@ -65,6 +65,16 @@ struct svi_ba {
 
     // ---- device ----
     hipStream_t stream = nullptr;
+    // The Schur reduction runs on a stream of its own while the factorisation of the early dependency levels already works on
+    // the stages it has finished (ba_host.cpp trial()).  The two streams are tied by VALUES IN MEMORY the command processor waits
+    // on (hipStreamWaitValue64 / hipStreamWriteValue64 on signal memory): a wave of k_schur that leaves a stage is counted, the
+    // last one publishes the trial's sequence number for that stage - no kernel ever spins on another stream's kernel.
+    hipStream_t stream_schur = nullptr;
+    unsigned long long* sig_lin = nullptr;                 // main -> Schur stream: the linearisation (and H_ll^-1) of this trial is ready
+    unsigned long long* sig_stage[svi::kMaxStages] = {};   // Schur stream -> main: stage s of this trial is reduced
+    unsigned long long stage_seq = 0;                      // sequence number of the last staged trial
+    bool overlap_ok = false;                               // the device supports stream waits on memory and the streams / signals exist
+    std::vector<int> sub_stage_ptr, level_stage;           // host mirrors of the stage ranges (sub-tiles, dependency levels)
     int spec_lin_state = -1;   // state whose Jacobian sweep + pose-only edges are already enqueued (speculation on "accepted"), or -1
     bool own_stream = false;
     bool host_stale = false; // an optimize() has run since the host copy of the estimates was refreshed (ensure_host)

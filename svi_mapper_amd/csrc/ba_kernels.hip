@@ -899,27 +899,40 @@ __device__ __forceinline__ void schur_stash(const SchurStage& st, int lane, doub
     }
 }
 
-__global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
+// a slab value leaves the XCD's L2 at once (write-through): the kernel that sums the slabs of a STAGE starts, on another stream,
+// while this kernel is still running - no kernel boundary writes the L2 back for it (MI355X_MICROARCH.md, publish-large:
+// write-through stores + a drained counter beat plain stores + a release fence)
+__device__ __forceinline__ void slab_store(double* p, double v, bool through)
+{
+    if (through) __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else *p = v;
+}
+
+__global__ __launch_bounds__(kBlock) void k_schur(BaDev d, int stage0, int stage1, StageSignals sg)
 {
     // The operands of kSchurBatch passes are staged in a wave-private LDS region, double buffered: the
     // global loads of batch k+1 are in flight while batch k is being multiplied out of LDS.
     // Block of pose pair (a,b) for one landmark, with M = N_a Hinv N_b' (3x3), Ka = 2[Z_a]x, Kb = 2[Z_b]x:
     //     H_pl,a Hinv H_pl,b' = [ M , -M Kb ; Ka M , -Ka M Kb ]
+    // Stages: a wave walks its job of stage0, then of stage0 + 1, ...; leaving a stage it drains its slab stores and arrives at
+    // the stage's counter, the last arrival publishes the stage (sg) - the consumers of a stage never wait for a later one.
     __shared__ double s_stage[kBlock / 64][2][kSchurBatch][4][kSchurSlot];
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int job = blockIdx.x * (kBlock / 64) + wave;
-    if (job >= d.n_jobs) return;
     const int qt = lane >> 4, i = (lane >> 2) & 3, j = lane & 3;
+    const int4* __restrict__ items = reinterpret_cast<const int4*>(d.it_pack);
+    const unsigned below_i = (1u << i) - 1u, below_j = (1u << j) - 1u;
+    const bool through = stage1 - stage0 > 1;
+    for (int stage = stage0; stage < stage1; ++stage) {
+    const int job = stage * d.n_jobs + blockIdx.x * (kBlock / 64) + wave;
     const int it0 = d.qj_begin[4 * job + qt], it1 = d.qj_end[4 * job + qt];
     const bool diag = d.qj_diag[4 * job + qt] != 0;
     const int n_pass = d.job_len[job];
-    const int4* __restrict__ items = reinterpret_cast<const int4*>(d.it_pack);
+    if (n_pass > 0) { // (wave-uniform; an empty slot of a short list leaves no slab: no cell lists it)
     double acc[36], gacc[6];
 #pragma unroll
     for (int q = 0; q < 36; ++q) acc[q] = 0.0;
 #pragma unroll
     for (int q = 0; q < 6; ++q) gacc[q] = 0.0;
-    const unsigned below_i = (1u << i) - 1u, below_j = (1u << j) - 1u;
     // three stages in flight: item records of batch k+2, operands of batch k+1 (registers), batch k (LDS) being multiplied
     SchurStage st;
     int4 pk[kSchurBatch];
@@ -1016,21 +1029,36 @@ __global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
         __builtin_amdgcn_wave_barrier();
         SCHUR_PIN
     }
-    if (d.job_merged[job] != 0) { // (wave-uniform) four pieces of one cell: (q0 + q1) + (q2 + q3) in every lane, read from quarter 0
+    const bool merged = d.job_merged[job] != 0;
+    if (merged) { // (wave-uniform) four pieces of one cell: (q0 + q1) + (q2 + q3) in every lane, read from quarter 0
 #pragma unroll
         for (int q = 0; q < 36; ++q) { double v = acc[q]; v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); acc[q] = v; }
 #pragma unroll
         for (int q = 0; q < 6; ++q) { double v = gacc[q]; v += __shfl_xor(v, 16); v += __shfl_xor(v, 32); gacc[q] = v; }
     }
-    const bool merged = d.job_merged[job] != 0;
     double* out = d.slab + (size_t)job * 36 * 64;
     if (!merged || qt == 0) { // (a merged wave: only its first quarter is ever read)
 #pragma unroll
-        for (int q = 0; q < 36; ++q) out[q * 64 + lane] = acc[q];
+        for (int q = 0; q < 36; ++q) slab_store(out + q * 64 + lane, acc[q], through);
     }
     if (diag && i == j && (!merged || qt == 0)) {
 #pragma unroll
-        for (int q = 0; q < 6; ++q) d.gslab[((size_t)(4 * job + qt) * 6 + q) * 4 + i] = gacc[q];
+        for (int q = 0; q < 6; ++q) slab_store(d.gslab + ((size_t)(4 * job + qt) * 6 + q) * 4 + i, gacc[q], through);
+    }
+    }
+    if (through) {
+        // every store of this wave has left for memory before the wave is counted; the last arrival of a stage (the counter goes
+        // back to zero for the next launch) tells whoever waits on the stage's value
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (lane == 0) {
+            const int total = (int)gridDim.x * (kBlock / 64);
+            const int k = __hip_atomic_fetch_add(d.stage_count + stage, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (k == total - 1) {
+                __hip_atomic_store(d.stage_count + stage, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (sg.sig[stage]) __hip_atomic_store(sg.sig[stage], sg.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
     }
 }
 
@@ -1041,12 +1069,14 @@ __global__ __launch_bounds__(kBlock) void k_schur(BaDev d)
 // ---------------------------------------------------------------------------------------------
 constexpr int kAsmThreads = 512; // eight waves: the quarter-job slabs of a cell are shared by all of them
 
-__global__ __launch_bounds__(kAsmThreads) void k_assemble(BaDev d)
+// sub0: first sub-tile of this launch (a stage's range, or 0).  accumulate: the tile and g were zeroed at the start of the trial
+// and may already carry updates of the factorisation's earlier levels (a later stage is assembled while those run): add, do not store.
+__global__ __launch_bounds__(kAsmThreads) void k_assemble(BaDev d, int sub0, int accumulate)
 {
     __shared__ double s_t[48][49];
     constexpr int NWA = kAsmThreads / 64;
     __shared__ double s_part[NWA][36 * 16];
-    const int sub = blockIdx.x, tid = threadIdx.x;
+    const int sub = sub0 + (int)blockIdx.x, tid = threadIdx.x;
     const int cx = d.sub_cx[sub], cy = d.sub_cy[sub], n = 6 * d.Pf, TS = d.TS;
     // several ranks, pose sums not exchanged on their own: this rank's chi2 of the linearisation rides in front of g
     // (rewritten per trial: the all-reduce leaves the total there)
@@ -1145,7 +1175,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(BaDev d)
         const int r = e / 48, c = e % 48;
         double v = s_t[r][c];
         if (R0 + r >= n || C0 + c >= n) v = (R0 + r == C0 + c) ? 1.0 : 0.0; // identity padding
-        out[(size_t)r * TS + c] = v;
+        if (accumulate) out[(size_t)r * TS + c] += v; else out[(size_t)r * TS + c] = v;
     }
     if (cx == cy) {
         // right-hand side: row r of the sub-tile collects the g slabs of its diagonal cell.  Five threads per row share
@@ -1183,7 +1213,7 @@ __global__ __launch_bounds__(kAsmThreads) void k_assemble(BaDev d)
 #pragma unroll
                 for (int part = 0; part < GP; ++part) v += s_gp[part * 48 + r];
             }
-            d.g[row] = v;
+            if (accumulate) d.g[row] += v; else d.g[row] = v;
         }
     }
 }
@@ -1550,13 +1580,16 @@ void ba_invert_landmarks(const BaDev& d, double lambda, void* st)
 {
     if (d.Ll > 0) hipLaunchKernelGGL(k_invert_landmarks, dim3((d.Ll + kBlock - 1) / kBlock), dim3(kBlock), 0, S_(st), d, lambda);
 }
-void ba_schur(const BaDev& d, void* st)
+// all stages in one launch; sg (optional): the values a waiting stream is released by, stage by stage
+void ba_schur(const BaDev& d, const StageSignals* sg, void* st)
 {
-    if (d.n_jobs > 0) hipLaunchKernelGGL(k_schur, dim3((d.n_jobs + 3) / 4), dim3(kBlock), 0, S_(st), d);
+    StageSignals none{};
+    if (d.n_jobs > 0) hipLaunchKernelGGL(k_schur, dim3((d.n_jobs + 3) / 4), dim3(kBlock), 0, S_(st), d, 0, d.n_stages, sg ? *sg : none);
 }
-void ba_assemble(const BaDev& d, void* st)
+// sub-tiles [sub0, sub1)
+void ba_assemble(const BaDev& d, int sub0, int sub1, int accumulate, void* st)
 {
-    if (d.n_sub > 0) hipLaunchKernelGGL(k_assemble, dim3(d.n_sub), dim3(kAsmThreads), 0, S_(st), d);
+    if (sub1 > sub0) hipLaunchKernelGGL(k_assemble, dim3(sub1 - sub0), dim3(kAsmThreads), 0, S_(st), d, sub0, accumulate);
 }
 void ba_update_poses(const BaDev& d, int cur, double lambda, int scale_mode, int rank, void* st)
 {

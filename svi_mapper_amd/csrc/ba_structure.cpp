@@ -97,7 +97,9 @@ struct Build {
         h_tgt_ptr, tgt_tile, tgt_row, tgt_pair_ptr, pair_a, pair_b, pair_src, h_trsm_ptr, st_tile, st_col;
     double chol_flops = 0.0;
     // Schur
-    int n_sub = 0, n_items = 0, n_jobs = 0;
+    int n_sub = 0, n_items = 0, n_jobs = 0; // n_jobs: wavefront jobs PER STAGE (the kernel's grid), n_stages of them back to back
+    int n_stages = 1, schur_wgs = 0;
+    std::vector<int> level_stage, sub_stage_ptr; // stage of every dependency level; sub-tiles [sub_stage_ptr[s], sub_stage_ptr[s+1]) belong to stage s
     int64_t total_pairs = 0;
     std::vector<int> sub_cx, sub_cy, sub_tile, it_pack, qj_begin, qj_end, qj_diag, job_len, job_merged, cell_qj_ptr, cell_qj, sub_aux_ptr, sub_aux_ref;
 
@@ -117,7 +119,8 @@ struct Build {
         pre_col.clear(); h_tgt_ptr.clear(); tgt_tile.clear(); tgt_row.clear(); tgt_pair_ptr.clear(); pair_a.clear();
         pair_b.clear(); pair_src.clear(); h_trsm_ptr.clear(); st_tile.clear(); st_col.clear(); sub_cx.clear(); sub_cy.clear();
         sub_tile.clear(); it_pack.clear(); qj_begin.clear(); qj_end.clear(); qj_diag.clear(); job_len.clear(); job_merged.clear();
-        cell_qj_ptr.clear(); cell_qj.clear(); sub_aux_ptr.clear(); sub_aux_ref.clear();
+        cell_qj_ptr.clear(); cell_qj.clear(); sub_aux_ptr.clear(); sub_aux_ref.clear(); level_stage.clear(); sub_stage_ptr.clear();
+        n_stages = 1; schur_wgs = 0;
         Pn = Pf = Ltot = 0; Etot = 0; use_cpl = false; span = 0; L0 = Ll = E = Epm = 0; n_lm_blocks = n_chunks = 0; planes = 3;
         TS = 96; PB = 16; n = NT = n_tiles = n_tiles_orig = n_steps = 0; chol_flops = 0.0; n_sub = n_items = n_jobs = 0; total_pairs = 0;
     }
@@ -692,16 +695,52 @@ int schur_work_lists(Build& b)
     svi_ba* ba = b.ba;
     constexpr int PBS = 8, SUB = 48, PQ = 4;
     const int TS = b.TS, NT = b.NT, Q = TS / SUB, NSUB = NT * Q, Ll = b.Ll;
-    // stored sub-tiles: every lower sub-tile inside a stored tile (they all have to be (re)written per trial)
-    std::vector<int> sub_map((size_t)NSUB * NSUB, -1);
-    for (int t = 0; t < b.n_tiles; ++t)
-        for (int sx = 0; sx < Q; ++sx)
-            for (int sy = 0; sy < Q; ++sy) {
-                const int cx = b.tile_ti[t] * Q + sx, cy = b.tile_tj[t] * Q + sy;
-                if (cy > cx) continue;
-                sub_map[(size_t)cx * NSUB + cy] = (int)b.sub_cx.size();
-                b.sub_cx.push_back(cx); b.sub_cy.push_back(cy); b.sub_tile.push_back(t);
+    // Stages.  The reduced system is wanted by the factorisation level by level (ba_chol.hip: one launch per dependency level), and
+    // the first levels - the leaves of the nested dissection - only need the tiles of THEIR columns.  The Schur work is therefore
+    // cut into stages by the level of a tile's column: every wave of k_schur walks its piece of stage 0, then of stage 1, ... and
+    // reports each stage as it leaves it, so that the factorisation of the early levels runs (on a second stream, behind a
+    // stream wait on a value in memory) while the later stages are still being reduced.  Stage boundaries: levels 1, 2, 4, 8
+    // (SVI_SCHUR_STAGES overrides, "0" = one stage); one stage where there is nothing to hide (few levels, several ranks - the
+    // all-reduce of the reduced system sits between reduction and factorisation there).
+    {
+        std::vector<int> bounds; // (off by default until the staged path beats the single launch: DESIGN.md section 9)
+        if (const char* e = getenv("SVI_SCHUR_STAGES")) {
+            bounds.clear();
+            for (const char* p = e; *p;) { char* q = nullptr; const long v = strtol(p, &q, 10); if (q == p) break; if (v > 0) bounds.push_back((int)v); p = (*q == ',') ? q + 1 : q; }
+        }
+        if (bounds.size() > (size_t)kMaxStages - 1) bounds.resize((size_t)kMaxStages - 1);
+        const bool staged = ba->opt.n_ranks == 1 && b.n_steps >= 5 && b.E >= 50000 && !bounds.empty();
+        b.level_stage.assign((size_t)std::max(b.n_steps, 1), 0);
+        b.n_stages = 1;
+        if (staged) {
+            std::sort(bounds.begin(), bounds.end());
+            int stage = 0;
+            size_t nb = 0;
+            for (int st = 0; st < b.n_steps; ++st) {
+                while (nb < bounds.size() && bounds[nb] <= st) { if (bounds[nb] > 0 && (nb == 0 || bounds[nb] != bounds[nb - 1])) ++stage; ++nb; }
+                b.level_stage[st] = stage;
             }
+            b.n_stages = stage + 1;
+        }
+    }
+    // stored sub-tiles: every lower sub-tile inside a stored tile (they all have to be (re)written per trial), by stage of the
+    // tile's column, then in tile order
+    std::vector<int> sub_map((size_t)NSUB * NSUB, -1);
+    b.sub_stage_ptr.assign((size_t)b.n_stages + 1, 0);
+    for (int stage = 0; stage < b.n_stages; ++stage) {
+        b.sub_stage_ptr[stage] = (int)b.sub_cx.size();
+        for (int t = 0; t < b.n_tiles; ++t) {
+            if (b.level_stage[b.level[b.tile_tj[t]]] != stage) continue;
+            for (int sx = 0; sx < Q; ++sx)
+                for (int sy = 0; sy < Q; ++sy) {
+                    const int cx = b.tile_ti[t] * Q + sx, cy = b.tile_tj[t] * Q + sy;
+                    if (cy > cx) continue;
+                    sub_map[(size_t)cx * NSUB + cy] = (int)b.sub_cx.size();
+                    b.sub_cx.push_back(cx); b.sub_cy.push_back(cy); b.sub_tile.push_back(t);
+                }
+        }
+    }
+    b.sub_stage_ptr[b.n_stages] = (int)b.sub_cx.size();
     b.n_sub = (int)b.sub_cx.size();
     const int n_cells = 4 * b.n_sub;
     b.mark(61);
@@ -794,82 +833,115 @@ int schur_work_lists(Build& b)
         }
     });
     b.mark(65);
-    // quarter jobs: as many as fit on the chip at once - the kernel holds two waves per SIMD (214 VGPRs, 59 KB of LDS per
-    // workgroup), one more would wait for a whole round.  Measured at config 4 with the current kernels (quarter jobs: Schur +
+    // quarter jobs: as many as fit on the chip at once - the kernel holds two waves per SIMD (212 VGPRs, 59 KB of LDS per
+    // workgroup), one more would wait for a whole round.  Measured at config 4 with the round-2 kernels (quarter jobs: Schur +
     // assemble us): 4096: 207 + 22, 6144: 185 + 27, 8192: 176 + 33, 10240: 209 + 38.
+    // With several stages the workgroups stay for the whole launch and the factorisation's workgroups (512 threads, 100 KB of
+    // LDS: they fit beside ONE Schur workgroup on a CU, not beside two) must find room while it runs: `reserve` CUs are left
+    // with a single Schur workgroup (SVI_SCHUR_RESERVE_CUS).
     int n_cu = 256;
     if (const int cu = device_compute_units(ba->opt.device)) n_cu = cu;
-    const int64_t qj_cap = (int64_t)4 * (n_cu * 4 * 2);
+    constexpr int NX = 8;
+    int reserve = 0;
+    if (b.n_stages > 1) {
+        reserve = n_cu / 4;
+        if (const char* e = getenv("SVI_SCHUR_RESERVE_CUS")) reserve = std::min(std::max(atoi(e), 0), n_cu);
+    }
+    const int wg_cap = std::max(NX, ((2 * n_cu - reserve) / NX) * NX); // workgroups of the launch (a multiple of the XCD count)
+    b.schur_wgs = wg_cap;
+    const int64_t qj_cap = (int64_t)16 * wg_cap;
     // XCD-aware placement.  Workgroups b and b + 8 share an XCD (its 4 MiB L2); an edge's operands are wanted by every cell of
     // its pose group's ROW (as row segment) and COLUMN (as column segment), 7-9 items in as many cells at config 4.  Dealt
     // round-robin, those cells end up on all eight XCDs and each of them fetches the edge over the fabric (700 MB per launch
     // against 77 MB of operands).  So the rows of cells are cut into eight contiguous ranges of equal work, one per XCD:
     // the row-segment re-reads all hit that XCD's L2, the column-segment re-reads mostly (band width < range width).
-    constexpr int NX = 8;
     const int NG = 2 * NSUB; // row groups of four poses
     auto row_group = [&](int c) { return 2 * b.sub_cx[c / 4] + (c / 2) % 2; };
-    std::vector<int> grp_pieces((size_t)NG), grp_x((size_t)NG);
-    int L = 16;
-    for (;; ++L) {
-        std::fill(grp_pieces.begin(), grp_pieces.end(), 0);
-        int64_t total = 0;
-        for (int c = 0; c < n_cells; ++c) { const int k = (cell_ptr[c + 1] - cell_ptr[c] + L - 1) / L; grp_pieces[row_group(c)] += k; total += k; }
-        // contiguous ranges of row groups with about total / NX pieces each
-        int64_t acc = 0, worst = 0, in_x = 0;
-        int x = 0;
-        for (int g = 0; g < NG; ++g) {
-            if (x < NX - 1 && in_x > 0 && (acc + grp_pieces[g] / 2) * NX > total * (x + 1)) { worst = std::max(worst, in_x); in_x = 0; ++x; }
-            grp_x[g] = x; acc += grp_pieces[g]; in_x += grp_pieces[g];
-        }
-        worst = std::max(worst, in_x);
-        if (L >= 1024 || (total <= qj_cap && worst <= qj_cap / NX)) break;
-    }
     struct QJob { int begin, end, cell; };
-    std::vector<QJob> qjobs;
-    for (int c = 0; c < n_cells; ++c)
-        for (int i = cell_ptr[c]; i < cell_ptr[c + 1]; i += L) qjobs.push_back({i, std::min(i + L, cell_ptr[c + 1]), c});
-    // inside an XCD waves take four quarter jobs of similar length; the slabs of a cell are summed in the order of its pieces
-    std::vector<int> xq[NX];
-    for (size_t i = 0; i < qjobs.size(); ++i) xq[grp_x[row_group(qjobs[i].cell)]].push_back((int)i);
+    std::vector<QJob> qjobs;                 // all stages, ascending in cell
+    std::vector<int> stage_q0((size_t)b.n_stages + 1, 0), stage_L((size_t)b.n_stages, 16);
+    std::vector<std::vector<int>> stage_grp_x((size_t)b.n_stages, std::vector<int>((size_t)NG, 0));
     int nblk = 0;
-    for (int x = 0; x < NX; ++x) {
-        // diagonal cells first: their waves carry the right-hand side (and skip the column segment), the others do neither
-        auto is_diag = [&](int q) { const int c = qjobs[q].cell, sub = c / 4; return b.sub_cx[sub] == b.sub_cy[sub] && (c / 2) % 2 == c % 2; };
-        std::stable_sort(xq[x].begin(), xq[x].end(), [&](int u, int v) {
-            const bool du = is_diag(u), dv = is_diag(v);
-            if (du != dv) return du;
-            return qjobs[u].end - qjobs[u].begin > qjobs[v].end - qjobs[v].begin;
-        });
-        nblk = std::max(nblk, ((int)xq[x].size() + 15) / 16);
+    for (int stage = 0; stage < b.n_stages; ++stage) {
+        const int c0 = 4 * b.sub_stage_ptr[stage], c1 = 4 * b.sub_stage_ptr[stage + 1];
+        std::vector<int> grp_pieces((size_t)NG);
+        std::vector<int>& grp_x = stage_grp_x[stage];
+        int L = 16;
+        for (;; ++L) {
+            std::fill(grp_pieces.begin(), grp_pieces.end(), 0);
+            int64_t total = 0;
+            for (int c = c0; c < c1; ++c) { const int k = (cell_ptr[c + 1] - cell_ptr[c] + L - 1) / L; grp_pieces[row_group(c)] += k; total += k; }
+            // contiguous ranges of row groups with about total / NX pieces each
+            int64_t acc = 0, worst = 0, in_x = 0;
+            int x = 0;
+            for (int g = 0; g < NG; ++g) {
+                if (x < NX - 1 && in_x > 0 && (acc + grp_pieces[g] / 2) * NX > total * (x + 1)) { worst = std::max(worst, in_x); in_x = 0; ++x; }
+                grp_x[g] = x; acc += grp_pieces[g]; in_x += grp_pieces[g];
+            }
+            worst = std::max(worst, in_x);
+            if (L >= 1024 || (total <= qj_cap && worst <= qj_cap / NX)) break;
+        }
+        stage_L[stage] = L;
+        stage_q0[stage] = (int)qjobs.size();
+        for (int c = c0; c < c1; ++c)
+            for (int i = cell_ptr[c]; i < cell_ptr[c + 1]; i += L) qjobs.push_back({i, std::min(i + L, cell_ptr[c + 1]), c});
     }
-    b.n_jobs = NX * nblk * 4; // workgroup 8 i + x = the i-th group of sixteen quarter jobs of XCD x (empty ones pad the short lists)
-    const size_t nq4 = (size_t)4 * std::max(b.n_jobs, 1);
+    stage_q0[b.n_stages] = (int)qjobs.size();
+    // inside an XCD waves take four quarter jobs of similar length; the slabs of a cell are summed in the order of its pieces
+    std::vector<std::vector<int>> xq((size_t)b.n_stages * NX);
+    auto is_diag = [&](int q) { const int c = qjobs[q].cell, sub = c / 4; return b.sub_cx[sub] == b.sub_cy[sub] && (c / 2) % 2 == c % 2; };
+    for (int stage = 0; stage < b.n_stages; ++stage) {
+        for (int i = stage_q0[stage]; i < stage_q0[stage + 1]; ++i) xq[(size_t)stage * NX + stage_grp_x[stage][row_group(qjobs[i].cell)]].push_back(i);
+        for (int x = 0; x < NX; ++x) {
+            std::vector<int>& v = xq[(size_t)stage * NX + x];
+            // diagonal cells first: their waves carry the right-hand side (and skip the column segment), the others do neither
+            std::stable_sort(v.begin(), v.end(), [&](int u, int w) {
+                const bool du = is_diag(u), dw = is_diag(w);
+                if (du != dw) return du;
+                return qjobs[u].end - qjobs[u].begin > qjobs[w].end - qjobs[w].begin;
+            });
+            nblk = std::max(nblk, ((int)v.size() + 15) / 16);
+        }
+    }
+    // one grid for all stages: workgroup 8 i + x = the i-th group of sixteen quarter jobs of XCD x in EVERY stage (empty ones pad
+    // the short lists); job slot of stage s = s * n_jobs + (job inside the stage)
+    b.n_jobs = NX * nblk * 4;
+    const size_t nq4s = (size_t)4 * std::max(b.n_jobs, 1);            // quarter-job slots per stage
+    const size_t nq4 = nq4s * (size_t)b.n_stages;
+    const size_t n_jobs_all = (size_t)std::max(b.n_jobs, 1) * (size_t)b.n_stages;
     b.qj_begin.assign(nq4, 0); b.qj_end.assign(nq4, 0); b.qj_diag.assign(nq4, 0);
-    b.job_len.assign(std::max(b.n_jobs, 1), 0);
+    b.job_len.assign(n_jobs_all, 0);
     std::vector<int> slot_of(qjobs.size(), -1), slot_cell(nq4, -1);
-    for (int x = 0; x < NX; ++x)
-        for (size_t j = 0; j < xq[x].size(); ++j) {
-            const QJob& q = qjobs[xq[x][j]];
-            const size_t k = ((size_t)(NX * (j / 16) + x) * 4 + (j / 4) % 4) * 4 + j % 4;
-            b.qj_begin[k] = q.begin; b.qj_end[k] = q.end;
-            const int sub = q.cell / 4, u = (q.cell / 2) % 2, v = q.cell % 2;
-            b.qj_diag[k] = (b.sub_cx[sub] == b.sub_cy[sub] && u == v) ? 1 : 0;
-            b.job_len[k / 4] = std::max(b.job_len[k / 4], q.end - q.begin);
-            slot_of[xq[x][j]] = (int)k;
-            slot_cell[k] = q.cell;
+    for (int stage = 0; stage < b.n_stages; ++stage)
+        for (int x = 0; x < NX; ++x) {
+            const std::vector<int>& v = xq[(size_t)stage * NX + x];
+            for (size_t j = 0; j < v.size(); ++j) {
+                const QJob& q = qjobs[v[j]];
+                const size_t k = nq4s * (size_t)stage + ((size_t)(NX * (j / 16) + x) * 4 + (j / 4) % 4) * 4 + j % 4;
+                b.qj_begin[k] = q.begin; b.qj_end[k] = q.end;
+                const int sub = q.cell / 4, u = (q.cell / 2) % 2, vv = q.cell % 2;
+                b.qj_diag[k] = (b.sub_cx[sub] == b.sub_cy[sub] && u == vv) ? 1 : 0;
+                b.job_len[k / 4] = std::max(b.job_len[k / 4], q.end - q.begin);
+                slot_of[v[j]] = (int)k;
+                slot_cell[k] = q.cell;
+            }
         }
     // A wave whose four quarter jobs belong to ONE cell (the full-length pieces of a hot cell are neighbours in the sorted lists)
     // adds its quarters up itself and leaves one slab instead of four: k_assemble walks a quarter of the list of a hot cell
     // (forty pieces of a diagonal cell was what its slowest workgroups waited for).  The order of the sums stays fixed.
-    b.job_merged.assign(std::max(b.n_jobs, 1), 0);
-    for (int job = 0; job < b.n_jobs; ++job) {
-        const int c0 = slot_cell[(size_t)4 * job];
-        b.job_merged[job] = (c0 >= 0 && slot_cell[(size_t)4 * job + 1] == c0 && slot_cell[(size_t)4 * job + 2] == c0 && slot_cell[(size_t)4 * job + 3] == c0) ? 1 : 0;
+    b.job_merged.assign(n_jobs_all, 0);
+    for (size_t job = 0; job < n_jobs_all; ++job) {
+        const int c0 = slot_cell[4 * job];
+        b.job_merged[job] = (c0 >= 0 && slot_cell[4 * job + 1] == c0 && slot_cell[4 * job + 2] == c0 && slot_cell[4 * job + 3] == c0) ? 1 : 0;
     }
     if (b.dbg) {
         int nm = 0, nonempty = 0;
-        for (int job = 0; job < b.n_jobs; ++job) { nm += b.job_merged[job]; nonempty += b.job_len[job] > 0; }
-        fprintf(stderr, "schur: %d jobs (%d with work), %d of them single-cell (merged slabs), piece length %d\n", b.n_jobs, nonempty, nm, L);
+        for (size_t job = 0; job < n_jobs_all; ++job) { nm += b.job_merged[job]; nonempty += b.job_len[job] > 0; }
+        fprintf(stderr, "schur: %d stages x %d jobs (%d with work), %d of them single-cell (merged slabs), %d workgroups (%d CUs keep room)\n", b.n_stages, b.n_jobs,
+                nonempty, nm, b.n_jobs / 4, reserve);
+        for (int stage = 0; stage < b.n_stages; ++stage)
+            fprintf(stderr, "  stage %d: sub-tiles %d, items %d, quarter jobs %d, piece length %d\n", stage, b.sub_stage_ptr[stage + 1] - b.sub_stage_ptr[stage],
+                    cell_ptr[4 * b.sub_stage_ptr[stage + 1]] - cell_ptr[4 * b.sub_stage_ptr[stage]], stage_q0[stage + 1] - stage_q0[stage], stage_L[stage]);
     }
     b.cell_qj_ptr.assign((size_t)n_cells + 1, 0);
     {
@@ -1003,8 +1075,12 @@ int upload(Build& b)
     SVI_TRY(up.up(b.qj_diag, &d.qj_diag));
     SVI_TRY(up.up(b.job_merged, &d.job_merged));
     SVI_TRY(up.up(b.job_len, &d.job_len));
-    SVI_TRY(up.alloc((size_t)std::max(n_jobs, 1) * 36 * 64, &d.slab, false));
-    SVI_TRY(up.alloc((size_t)std::max(n_jobs, 1) * 4 * 6 * 4, &d.gslab, false));
+    d.n_stages = b.n_stages;
+    SVI_TRY(up.alloc((size_t)std::max(n_jobs, 1) * b.n_stages * 36 * 64, &d.slab, false));
+    SVI_TRY(up.alloc((size_t)std::max(n_jobs, 1) * b.n_stages * 4 * 6 * 4, &d.gslab, false));
+    SVI_TRY(up.alloc((size_t)b.n_stages + 1, &d.stage_count));
+    ba->sub_stage_ptr = b.sub_stage_ptr;
+    ba->level_stage = b.level_stage;
     SVI_TRY(up.up(b.cell_qj_ptr, &d.cell_qj_ptr));
     SVI_TRY(up.up(b.cell_qj, &d.cell_qj));
     SVI_TRY(up.up(b.sub_cx, &d.sub_cx));

@@ -6,6 +6,7 @@
 // never linked into libsvi_hot.so.
 #include <hip/hip_runtime_api.h>
 
+#include <cstdint>
 #include <cstdlib>
 #include <cstring>
 
@@ -21,6 +22,11 @@ hipError_t hipHostFree(void* p) { std::free(p); return hipSuccess; }
 hipError_t hipMemcpyAsync(void* d, const void* s, size_t n, hipMemcpyKind, hipStream_t) { if (n) std::memcpy(d, s, n); return hipSuccess; }
 hipError_t hipMemsetAsync(void* d, int v, size_t n, hipStream_t) { if (n) std::memset(d, v, n); return hipSuccess; }
 hipError_t hipStreamCreateWithFlags(hipStream_t* s, unsigned) { *s = nullptr; return hipSuccess; }
+hipError_t hipStreamCreateWithPriority(hipStream_t* s, unsigned, int) { *s = nullptr; return hipSuccess; }
+hipError_t hipDeviceGetStreamPriorityRange(int* lo, int* hi) { *lo = 0; *hi = 0; return hipSuccess; }
+hipError_t hipExtMallocWithFlags(void** p, size_t n, unsigned) { *p = std::calloc(1, n ? n : 1); return *p ? hipSuccess : hipErrorOutOfMemory; }
+hipError_t hipStreamWaitValue64(hipStream_t, void*, uint64_t, unsigned, uint64_t) { return hipSuccess; }
+hipError_t hipStreamWriteValue64(hipStream_t, void* p, uint64_t v, unsigned) { *static_cast<uint64_t*>(p) = v; return hipSuccess; }
 hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 hipError_t hipStreamQuery(hipStream_t) { return hipSuccess; }
