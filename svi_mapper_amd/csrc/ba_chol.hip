@@ -82,6 +82,14 @@ __device__ __forceinline__ void tile_load(const double* __restrict__ g, TileRegs
     }
 }
 
+// a += b (the assembled tile and the updates the factorisation has accumulated for it live in two arrays when the reduction is staged)
+template <int TS>
+__device__ __forceinline__ void tile_add(TileRegs<TS>& a, const TileRegs<TS>& b)
+{
+#pragma unroll
+    for (int it = 0; it < TileRegs<TS>::IT; ++it) { a.v[it].x += b.v[it].x; a.v[it].y += b.v[it].y; }
+}
+
 template <int TS>
 __device__ __forceinline__ void tile_store(const TileRegs<TS>& t, double* s)
 {
@@ -214,8 +222,11 @@ __device__ __forceinline__ int unpack_nibble(unsigned packed, int wave) { return
 // below accumulate into the same registers, and nothing is computed 16 times over.  Columns <= the pivot are kept
 // out of an update by zeroing the operand, so an accumulator column always ends as the unscaled factor column.
 // ---------------------------------------------------------------------------------------------
-template <int TS>
-__device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, double* __restrict__ Lg, double* sL, double* sX,
+// SPLIT: the reduced system comes in two arrays - S (assembled by the Schur kernel, never written here) and Su (what the levels
+// below have subtracted so far, zero at the start of a trial): every tile is read as S + Su, every update goes to Su.  The Schur
+// reduction of a later stage may then still be writing ITS tiles of S while earlier levels already update them (ba_host.cpp).
+template <int TS, bool SPLIT>
+__device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, const double* __restrict__ Au, const double* __restrict__ Su_all, double* __restrict__ Lg, double* sL, double* sX,
                                                  double (*s_col)[TS][4], double* s_rs, int k, int n, double lambda, int stop_after,
                                                  double* __restrict__ y, double* __restrict__ Lt, const int* __restrict__ pre_tile_g,
                                                  const int* __restrict__ pre_col_g, int npre, double* s_g, const double* __restrict__ S_all,
@@ -257,7 +268,9 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const int r = 16 * ba[u] + lk + 4 * q, c = 16 * bb[u] + ln;
-            acc[u][q] = own[u] ? A[r * TS + c] : 0.0; // (lambda goes on below: nothing may consume this load before the others are issued)
+            // (lambda goes on below: nothing may consume this load before the others are issued)
+            if constexpr (SPLIT) acc[u][q] = own[u] ? A[r * TS + c] + Au[r * TS + c] : 0.0;
+            else acc[u][q] = own[u] ? A[r * TS + c] : 0.0;
         }
     }
     // pending updates of this tile from the columns of the level just below: A -= L(k,q) L(k,q)' and the forward
@@ -269,15 +282,17 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
     if constexpr (Fold<TS>::on) {
         // L(k,q) = S(k,q) L_qq^-T is formed here (no k_trsm launch): S(k,q) -> sX, L_qq^-1 -> sL, the product -> sT and, for
         // the backward substitution, to its tile of Lt
-        TileRegs<TS> ps, px;
+        TileRegs<TS> ps, px, pu;
         double ypre = 0.0;
         if (npre > 0) {
             tile_load<TS>(S_all + (size_t)pre_tile(0) * TS * TS, ps);
+            if constexpr (SPLIT) tile_load<TS>(Su_all + (size_t)pre_tile(0) * TS * TS, pu);
             tile_load<TS>(Linv_all + (size_t)pre_col(0) * TS * TS, px);
             if (tid < TS) ypre = y[pre_col(0) * TS + tid];
         }
         if (failed_before != 0) return kAborted; // an earlier column failed: nothing more to do in this trial
         for (int w = 0; w < npre; ++w) {
+            if constexpr (SPLIT) tile_add<TS>(ps, pu);
             tile_store<TS>(ps, sX);
             tile_store<TS>(px, sL);
             if (tid < TS) s_rs[tid] = ypre;
@@ -286,6 +301,7 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, do
             double* Lout = Lt + (size_t)pre_tile(w) * TS * TS;
             if (w + 1 < npre) { // the next source travels while this one is multiplied
                 tile_load<TS>(S_all + (size_t)pre_tile(w + 1) * TS * TS, ps);
+                if constexpr (SPLIT) tile_load<TS>(Su_all + (size_t)pre_tile(w + 1) * TS * TS, pu);
                 tile_load<TS>(Linv_all + (size_t)pre_col(w + 1) * TS * TS, px);
                 if (tid < TS) ypre = y[pre_col(w + 1) * TS + tid];
             }
@@ -499,18 +515,19 @@ struct StepArgs {
     ChainInline inl;             // the chain workgroups' records, if the level fits
 };
 
-template <int TS>
-__device__ void gemm_target_block(double* __restrict__ S, double* __restrict__ Lt, const double* __restrict__ Linv, const StepArgs& sa, int work,
-                                  double* __restrict__ g, const double* __restrict__ y, double* sm);
+template <int TS, bool SPLIT>
+__device__ void gemm_target_block(double* __restrict__ S, double* __restrict__ Su, double* __restrict__ Lt, const double* __restrict__ Linv, const StepArgs& sa, int work,
+                                  double* __restrict__ g, double* __restrict__ gu, const double* __restrict__ y, double* sm);
 
 // One dependency level of the factorisation.  Workgroups 0..n_chain-1 are the critical path: each applies the
 // pending updates of its diagonal tile from the level just below, then factorises it (potrf + inverse + y_k).
 // The other workgroups carry every remaining update whose source column sits in the level just below, grouped
 // by target tile - nothing on the critical path waits for them inside this launch.
-template <int TS>
+template <int TS, bool SPLIT = false>
 __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict__ S, double* __restrict__ Lt, double* __restrict__ Linv,
                                                              double* __restrict__ g, double* __restrict__ y, int n, double lambda,
-                                                             int* status, int stop_after, StepArgs sa, double* xs)
+                                                             int* status, int stop_after, StepArgs sa, double* xs, double* __restrict__ Su,
+                                                             double* __restrict__ gu)
 {
     constexpr int NB = TS / 16, LD = Lds<TS>::LD;
     extern __shared__ __align__(16) double sm[];
@@ -531,7 +548,7 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
     TS_MARK(0);
     if ((int)blockIdx.x >= sa.n_chain) {
         if (*status != 0) return;
-        gemm_target_block<TS>(S, Lt, Linv, sa, (int)blockIdx.x - sa.n_chain, g, y, sm);
+        gemm_target_block<TS, SPLIT>(S, Su, Lt, Linv, sa, (int)blockIdx.x - sa.n_chain, g, gu, y, sm);
         return;
     }
     // the column record: out of the kernel arguments when the level fits there (no index load in front of the tile loads),
@@ -561,9 +578,9 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
     double gk = 0.0;
     {
         const int gt = tid - (kPotrfThreads - 64 * ((TS + 63) / 64)); // (the sweep keeps g_k on the last wave(s))
-        if (gt >= 0 && gt < TS) gk = g[k * TS + gt];
+        if (gt >= 0 && gt < TS) { gk = g[k * TS + gt]; if constexpr (SPLIT) gk += gu[k * TS + gt]; }
     }
-    const int rc = potrf_sweep_mfma<TS>(A, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y, Lt, sa.pre_tile + pre0, sa.pre_col + pre0, npre, s_g, S,
+    const int rc = potrf_sweep_mfma<TS, SPLIT>(A, SPLIT ? Su + (size_t)tile_id * TS * TS : nullptr, Su, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y, Lt, sa.pre_tile + pre0, sa.pre_col + pre0, npre, s_g, S,
                                         Linv, sm + 2 * TS * LD, status, it0, it1, ic0, ic1, gk, s_cf);
     if (rc == 2) return;                                  // an earlier column of this trial had failed
     if (rc == 1) { if (tid == 0) *status = k + 1; return; } // not positive definite
@@ -774,9 +791,9 @@ __global__ __launch_bounds__(kBlock) void k_trsm(const double* __restrict__ S, d
 // accumulators across the sources, the tile is read-modified-written once.
 // ---------------------------------------------------------------------------------------------
 
-template <int TS>
-__device__ void gemm_target_block(double* __restrict__ S, double* __restrict__ Lt, const double* __restrict__ Linv, const StepArgs& sa, int work,
-                                  double* __restrict__ g, const double* __restrict__ y, double* sm)
+template <int TS, bool SPLIT>
+__device__ void gemm_target_block(double* __restrict__ S, double* __restrict__ Su, double* __restrict__ Lt, const double* __restrict__ Linv, const StepArgs& sa, int work,
+                                  double* __restrict__ g, double* __restrict__ gu, const double* __restrict__ y, double* sm)
 {
     if constexpr (Fold<TS>::on) {
         // tile edge 48 = one output block per target: the operand tiles L(i,q), L(j,q) are formed here from S and L_qq^-1
@@ -796,15 +813,20 @@ __device__ void gemm_target_block(double* __restrict__ S, double* __restrict__ L
         v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
         double gacc = 0.0;
         const bool g_thread = row >= 0 && threadIdx.x >= 64 && threadIdx.x < 64 + TS;
-        TileRegs<TS> ra, rb, rx;
+        TileRegs<TS> ra, rb, rx, rau, rbu;
         auto fetch = [&](int q) {
             tile_load<TS>(S + (size_t)sa.pair_a[q] * TS * TS, ra);
             if (sa.pair_b[q] != sa.pair_a[q]) tile_load<TS>(S + (size_t)sa.pair_b[q] * TS * TS, rb);
+            if constexpr (SPLIT) {
+                tile_load<TS>(Su + (size_t)sa.pair_a[q] * TS * TS, rau);
+                if (sa.pair_b[q] != sa.pair_a[q]) tile_load<TS>(Su + (size_t)sa.pair_b[q] * TS * TS, rbu);
+            }
             tile_load<TS>(Linv + (size_t)sa.pair_src[q] * TS * TS, rx);
         };
         if (p0 < p1) fetch(p0);
         for (int q = p0; q < p1; ++q) {
             const bool same = sa.pair_a[q] == sa.pair_b[q]; // uniform
+            if constexpr (SPLIT) { tile_add<TS>(ra, rau); if (!same) tile_add<TS>(rb, rbu); }
             tile_store<TS>(ra, sSa);
             if (!same) tile_store<TS>(rb, sSb);
             tile_store<TS>(rx, sXq);
@@ -840,7 +862,7 @@ __device__ void gemm_target_block(double* __restrict__ S, double* __restrict__ L
             }
             __syncthreads();
         }
-        double* C = S + (size_t)sa.tgt_tile[t] * TS * TS;
+        double* C = (SPLIT ? Su : S) + (size_t)sa.tgt_tile[t] * TS * TS;
         {
             const int st0 = wave, st1 = wave + NWV;
             const int r0 = (st0 / 3) * 16, c0 = (st0 % 3) * 16;
@@ -852,7 +874,7 @@ __device__ void gemm_target_block(double* __restrict__ S, double* __restrict__ L
                 for (int q = 0; q < 4; ++q) C[(size_t)(r1 + (lane >> 4) + 4 * q) * TS + c1 + (lane & 15)] -= acc1[q];
             }
         }
-        if (g_thread) g[row * TS + (threadIdx.x - 64)] -= gacc;
+        if (g_thread) (SPLIT ? gu : g)[row * TS + (threadIdx.x - 64)] -= gacc;
         return;
     } else {
     constexpr int LD = Lds<TS>::LD, Q = TS / kOB;
@@ -1279,8 +1301,9 @@ __global__ __launch_bounds__(kPotrfThreads) void k_back_solve_all(const SolveRec
 // levels [st_begin, st_end) of the factorisation, then (solve) the backward substitution
 template <int TS>
 int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n, int* status, hipStream_t s,
-        const PoseTail* tail, int* tail_done, int st_begin, int st_end, bool solve)
+        const PoseTail* tail, int* tail_done, int st_begin, int st_end, bool solve, double* Su = nullptr, double* gu = nullptr)
 {
+    const bool split = TS == 48 && Su != nullptr;
     if (tail_done) *tail_done = 0;
     // one-launch backward substitution (tile 48, every column's list short enough): the forward vector then lives in p.ybuf and
     // the solution vector carries "pending" markers until its entries are computed
@@ -1293,7 +1316,8 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
     static bool attr = false;
     if (!attr) {
         // a workgroup asking for more LDS than the CU has faults the queue: refuse instead of launching
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv<TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p) != hipSuccess ||
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv<TS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p) != hipSuccess ||
+            hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv<TS, TS == 48>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p) != hipSuccess ||
             hipFuncSetAttribute(reinterpret_cast<const void*>(k_trsm<TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_g) != hipSuccess)
             return 1;
         attr = true;
@@ -1308,7 +1332,8 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
         sa.n_chain = nc; sa.last_level = st == p.n_steps - 1; sa.chain_col = p.step_col + c0; sa.chain_desc = reinterpret_cast<const int4*>(p.step_desc) + 2 * c0;
         sa.tgt_tile = p.tgt_tile + t0; sa.tgt_row = p.tgt_row + t0; sa.tgt_pair_ptr = p.tgt_pair_ptr + t0;
         if (p.h_chain_inl) sa.inl = p.h_chain_inl[st]; else sa.inl.n = 0;
-        hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(nc + ntg * Q * Q), dim3(kPotrfThreads), lds_p, s, S, Lt, Linv, g, yv, n, lambda, status, 0, sa, x);
+        if (split) hipLaunchKernelGGL((k_potrf_inv<TS, TS == 48>), dim3(nc + ntg * Q * Q), dim3(kPotrfThreads), lds_p, s, S, Lt, Linv, g, yv, n, lambda, status, 0, sa, x, Su, gu);
+        else hipLaunchKernelGGL((k_potrf_inv<TS, false>), dim3(nc + ntg * Q * Q), dim3(kPotrfThreads), lds_p, s, S, Lt, Linv, g, yv, n, lambda, status, 0, sa, x, nullptr, nullptr);
         const int i0 = p.h_trsm_ptr[st], ni = p.h_trsm_ptr[st + 1] - i0;
         if (ni > 0 && !Fold<TS>::on) hipLaunchKernelGGL(k_trsm<TS>, dim3(ni * QT * QT), dim3(kBlock), lds_g, s, S, Lt, Linv, p.st_tile + i0, p.st_col + i0, status);
     }
@@ -1361,7 +1386,7 @@ static int potrf_probe(int reps, int stop_after, double* ms_out)
 {
     constexpr int LD = Lds<TS>::LD;
     const size_t lds_p = sizeof(double) * (Fold<TS>::on ? 5 : 2) * (size_t)TS * LD;
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv<TS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p) != hipSuccess) return 1;
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(k_potrf_inv<TS, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_p) != hipSuccess) return 1;
     double *S = nullptr, *L = nullptr, *X = nullptr, *g = nullptr, *y = nullptr;
     int *st = nullptr, *tab = nullptr; // tab: an all-zero column record (column 0, tile 0, nothing pending)
     std::vector<double> h((size_t)TS * TS);
@@ -1377,9 +1402,9 @@ static int potrf_probe(int reps, int stop_after, double* ms_out)
     (void)hipMemset(g, 0, sizeof(double) * TS); (void)hipMemset(st, 0, sizeof(int));
     hipEvent_t a, b;
     (void)hipEventCreate(&a); (void)hipEventCreate(&b);
-    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(1), dim3(kPotrfThreads), lds_p, 0, S, L, X, g, y, TS, 0.0, st, stop_after, sa, y);
+    for (int i = 0; i < 20; ++i) hipLaunchKernelGGL((k_potrf_inv<TS, false>), dim3(1), dim3(kPotrfThreads), lds_p, 0, S, L, X, g, y, TS, 0.0, st, stop_after, sa, y, nullptr, nullptr);
     (void)hipEventRecord(a, 0);
-    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL(k_potrf_inv<TS>, dim3(1), dim3(kPotrfThreads), lds_p, 0, S, L, X, g, y, TS, 0.0, st, stop_after, sa, y);
+    for (int i = 0; i < reps; ++i) hipLaunchKernelGGL((k_potrf_inv<TS, false>), dim3(1), dim3(kPotrfThreads), lds_p, 0, S, L, X, g, y, TS, 0.0, st, stop_after, sa, y, nullptr, nullptr);
     (void)hipEventRecord(b, 0);
     (void)hipEventSynchronize(b);
     float ms = 0.f;
@@ -1413,11 +1438,12 @@ int chol_factor_solve(const CholPlan& p, double* S, double* Lt, double* Linv, do
 }
 
 // the same in pieces: levels [st_begin, st_end) only; the backward substitution (and the trial poses) behind the last piece
+// Su / gu (tile 48, optional): the updates go to these arrays instead of into S / g (see potrf_sweep_mfma)
 int chol_factor_range(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n, int* status,
-                      void* st, const PoseTail* tail, int* tail_done, int st_begin, int st_end, int solve)
+                      void* st, const PoseTail* tail, int* tail_done, int st_begin, int st_end, int solve, double* Su, double* gu)
 {
     hipStream_t s = static_cast<hipStream_t>(st);
-    return p.TS == 48 ? run<48>(p, S, Lt, Linv, g, x, lambda, n, status, s, tail, tail_done, st_begin, st_end, solve != 0)
+    return p.TS == 48 ? run<48>(p, S, Lt, Linv, g, x, lambda, n, status, s, tail, tail_done, st_begin, st_end, solve != 0, Su, gu)
                       : run<96>(p, S, Lt, Linv, g, x, lambda, n, status, s, tail, tail_done, st_begin, st_end, solve != 0);
 }
 

@@ -24,6 +24,7 @@ enum : unsigned { kFlagTypeMask = 3u, kFlagRobust = 4u };
 constexpr int kLmBlockEdges = 256;   // lm-major kernels: one workgroup owns whole landmarks, <= 256 edges
 constexpr int kPoseChunk    = 1024;  // pose-major kernel: one workgroup sums <= 1024 edges of one pose
 constexpr int kMaxTile      = 96;
+constexpr int kMaxStages    = 8;     // stages of the Schur reduction
 
 struct BaDev {
     // camera / robust kernel
@@ -103,6 +104,8 @@ struct BaDev {
     double* g;             // red_buf: g[NT*TS] | tiles with contributions | fill-in tiles; the first red_count doubles
     double* S;             // = g + NT*TS : [n_tiles][TS*TS]                       (g + contributing tiles) are all-reduced per trial
     int     red_count;
+    double* upd[2];        // staged reduction only: [ g_upd[NT*TS] | S_upd[n_tiles][TS*TS] ], twice - what the factorisation has subtracted from
+                           // g / S so far in a trial (it reads g + g_upd, S + S_upd, ba_chol.hip); the two take turns from trial to trial
     double* Lt;            // [n_tiles][TS*TS] Cholesky factor tiles
     double* Linv;          // [NT][TS*TS] inverses of the diagonal Cholesky factors
     double* dx;            // [NT*TS] solution (pose increments)
@@ -113,6 +116,13 @@ struct BaDev {
     int n_items, n_jobs, n_sub; // n_jobs: wavefront jobs PER STAGE = 4 x the workgroups of k_schur; job slot = stage * n_jobs + job
     int n_stages;               // stages of the Schur reduction (by dependency level of a tile's column, ba_structure.cpp); 1 = unstaged
     int* stage_count;           // [n_stages] arrival counters of k_schur's waves (zero between launches)
+    int* ticket;                // [2][kMaxStages][8] staged launches: next group of quarter jobs per stage and XCD (two sets, by launch parity)
+    int* cell_count;            // [4 n_sub] slabs of a cell that have arrived (zero between launches): the last arrival assembles the cell
+    const int* qj_cell;         // [n_stages][4 n_jobs] cell a quarter job's slab belongs to, -1 if it leaves none
+    const int* orphan_ptr;      // [n_stages + 1] cells without any slab, by stage
+    const int* orphan_cell;
+    int asm_in_schur;           // 1: k_schur assembles the tiles itself (no k_assemble launch)
+    const BaDev* self;          // this structure in device memory (what a non-inlined device function reads the layout from)
     const int* it_pack;      // [n_items][4]: landmark, first edge of the row segment, first edge of the column segment, maskI | maskJ << 8
     const int* qj_begin;     // [n_stages][4 n_jobs] first item of quarter job 4 job + quarter
     const int* qj_end;       // [n_stages][4 n_jobs]
@@ -167,7 +177,6 @@ struct PoseTail {
 
 // what a wave of k_schur does when it leaves a stage: the last wave to arrive publishes `seq` at sig[stage] (memory a stream
 // waits on with hipStreamWaitValue64; nullptr: nobody waits)
-constexpr int kMaxStages = 8;
 struct StageSignals { unsigned long long* sig[kMaxStages]; unsigned long long seq; };
 
 struct CholPlan {

@@ -36,7 +36,7 @@ void ba_pose_finalize(const BaDev& d, const int* red_slot, int rank, int n_ranks
 void ba_publish(const BaDev& d, int n, double* h_scal, int* h_status, int seq, void* st);
 void ba_lin_post(const BaDev& d, int n_ranks, void* st);
 void ba_invert_landmarks(const BaDev& d, double lambda, void* st);
-void ba_schur(const BaDev& d, const StageSignals* sg, void* st);
+void ba_schur(const BaDev& d, const StageSignals* sg, unsigned long long seq, int reserve_per_se, int launch_wgs, void* st);
 void ba_assemble(const BaDev& d, int sub0, int sub1, int accumulate, void* st);
 void ba_update_poses(const BaDev& d, int cur, double lambda, int scale_mode, int rank, void* st);
 void ba_backsub_chi2(const BaDev& d, int cur, double lambda, void* st);
@@ -52,7 +52,7 @@ int chol_factor_solve(const CholPlan& p, double* S, double* Lt, double* Linv, do
 // svi_debug_set_backsolve_spin_limit: the tests shrink it to provoke the time-out path)
 std::atomic<int> g_backsolve_spin_limit{1 << 22};
 int chol_factor_range(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, double* x, double lambda, int n, int* status,
-                      void* st, const PoseTail* tail, int* tail_done, int st_begin, int st_end, int solve);
+                      void* st, const PoseTail* tail, int* tail_done, int st_begin, int st_end, int solve, double* Su, double* gu);
 int build_structure(svi_ba* ba); // ba_structure.cpp
 int reupload_state(svi_ba* ba);
 
@@ -269,11 +269,19 @@ int linearize(svi_ba* ba, bool read = true)
 // k_assemble with the pose terms matching what linearize() left in Hpp / bp: totals (rank 0 adds them) or this rank's share
 // stage < 0: every sub-tile.  With several stages the tiles and g start a trial as zeros (zero_reduced_system) and everything
 // that reaches them - the assembled blocks of their stage, the updates of the factorisation's levels - is added.
-void assemble(svi_ba* ba, int stage = -1)
+// the pose terms an assembly adds must match what linearize() left in Hpp / bp: totals (rank 0 adds them) or this rank's share;
+// set before the kernel that assembles is launched (k_schur itself, or k_assemble)
+void set_assembly_flags(svi_ba* ba)
 {
     BaDev& d = ba->d;
     d.add_pose_terms = (ba->lin_local || ba->opt.rank == 0) ? 1 : 0;
     d.lin_from_red = ba->lin_local ? 1 : 0;
+}
+
+void assemble(svi_ba* ba, int stage = -1)
+{
+    BaDev& d = ba->d;
+    if (d.asm_in_schur == 1) return; // (k_schur has written the tiles itself)
     const int acc = d.n_stages > 1 ? 1 : 0;
     if (stage < 0) ba_assemble(d, 0, d.n_sub, acc, ba->stream);
     else ba_assemble(d, ba->sub_stage_ptr[stage], ba->sub_stage_ptr[stage + 1], acc, ba->stream);
@@ -282,7 +290,7 @@ void assemble(svi_ba* ba, int stage = -1)
 int zero_reduced_system(svi_ba* ba)
 {
     BaDev& d = ba->d;
-    if (d.n_stages > 1 && d.NT > 0)
+    if (d.n_stages > 1 && d.asm_in_schur != 1 && d.NT > 0)
         SVI_HIP(hipMemsetAsync(d.g, 0, sizeof(double) * ((size_t)d.NT * d.TS + (size_t)d.n_tiles * d.TS * d.TS), ba->stream));
     return SVI_OK;
 }
@@ -290,7 +298,7 @@ int zero_reduced_system(svi_ba* ba)
 // the Schur reduction of a trial on its own stream, the factorisation level by level behind the stages it finishes
 bool use_overlap(const svi_ba* ba)
 {
-    static const bool off = getenv("SVI_NO_OVERLAP") != nullptr;
+    const bool off = getenv("SVI_NO_OVERLAP") != nullptr; // (read per trial: the tests switch it)
     return ba->overlap_ok && !off && ba->d.n_stages > 1 && ba->opt.n_ranks == 1 && !ba->timer.on;
 }
 
@@ -302,6 +310,7 @@ int trial(svi_ba* ba, double lambda, bool* failed, bool speculate = false)
     // (the status word is clean: whoever read it last cleared it)
     // the trial poses ride in the last launch of the solve (an extra workgroup that waits for its dx entries): a launch of their
     // own was 5 us + a boundary between the backward substitution and the landmark back-substitution (not while phases are timed)
+    set_assembly_flags(ba);
     const int scale_mode = ba->opt.n_ranks <= 1 ? 0 : (ba->lin_local ? 2 : 1);
     PoseTail tail{};
     tail.src = d.pose[ba->cur]; tail.dst = d.pose[ba->cur ^ 1]; tail.pose_red = d.pose_red; tail.bp = d.bp; tail.scal = d.scal;
@@ -312,12 +321,23 @@ int trial(svi_ba* ba, double lambda, bool* failed, bool speculate = false)
     static const bool no_spec = getenv("SVI_NO_SPECULATION") != nullptr;
     const PoseTail* tailp = (t.on || no_tail) ? nullptr : &tail;
     SVI_TRY(zero_reduced_system(ba));
+    // staged reduction with the tiles assembled by k_schur: the factorisation's updates go to d.upd[buf] (zero at this point)
+    const bool split = d.n_stages > 1 && d.asm_in_schur == 1 && d.upd[0] != nullptr && d.NT > 0;
+    const size_t upd_bytes = sizeof(double) * ((size_t)d.NT * d.TS + (size_t)d.n_tiles * d.TS * d.TS);
+    const int buf = (int)(ba->staged_trials & 1);
+    double *gu = nullptr, *Su = nullptr;
+    if (split) {
+        ++ba->staged_trials;
+        if (!ba->upd_clean[buf]) SVI_HIP(hipMemsetAsync(d.upd[buf], 0, upd_bytes, s));
+        ba->upd_clean[buf] = false;
+        gu = d.upd[buf]; Su = d.upd[buf] + (size_t)d.NT * d.TS;
+    }
     t.begin(SVI_PH_SCHUR, s);
     if (!(ba->hinv_valid && ba->hinv_lambda == lambda)) ba_invert_landmarks(d, lambda, s);
     ba->hinv_valid = false; // (a second trial of the iteration comes with another lambda)
     if (use_overlap(ba) && d.NT > 0) {
-        // main stream: "linearisation ready" -> Schur stream: k_schur, stage by stage -> main stream: per stage, assemble its
-        // sub-tiles and factorise the dependency levels whose columns it holds.  Only the first stage's wait is on the critical
+        // main stream: "linearisation ready" -> Schur stream: k_schur, stage by stage -> main stream: per stage, (assemble its
+        // sub-tiles and) factorise the dependency levels whose columns it holds.  Only the first stage's wait is on the critical
         // path: from then on the factorisation (17 launches, ~15 us each at config 4) is what the reduction has to keep ahead of.
         const unsigned long long seq = ++ba->stage_seq;
         StageSignals sg{};
@@ -325,7 +345,11 @@ int trial(svi_ba* ba, double lambda, bool* failed, bool speculate = false)
         sg.seq = seq;
         SVI_HIP(hipStreamWriteValue64(s, ba->sig_lin, seq, 0));
         SVI_HIP(hipStreamWaitValue64(ba->stream_schur, ba->sig_lin, seq, hipStreamWaitValueGte, ~0ull));
-        ba_schur(d, &sg, ba->stream_schur);
+        ba_schur(d, &sg, seq, ba->schur_reserve_per_se, ba->schur_launch_wgs, ba->stream_schur);
+        if (split) { // the other update buffer, for the next trial: zeroed here, where nothing waits for it
+            SVI_HIP(hipMemsetAsync(d.upd[buf ^ 1], 0, upd_bytes, ba->stream_schur));
+            ba->upd_clean[buf ^ 1] = true;
+        }
         SVI_HIP(hipGetLastError());
         const int n_steps = ba->plan.n_steps;
         int st = 0;
@@ -336,19 +360,19 @@ int trial(svi_ba* ba, double lambda, bool* failed, bool speculate = false)
             while (st1 < n_steps && ba->level_stage[st1] == stage) ++st1;
             const bool last = stage == d.n_stages - 1;
             if (last) st1 = n_steps;
-            if (chol_factor_range(ba->plan, d.S, d.Lt, d.Linv, d.g, d.dx, lambda, 6 * d.Pf, d.chol_status, s, tailp, &tail_done, st, st1, last ? 1 : 0) != 0)
+            if (chol_factor_range(ba->plan, d.S, d.Lt, d.Linv, d.g, d.dx, lambda, 6 * d.Pf, d.chol_status, s, tailp, &tail_done, st, st1, last ? 1 : 0, Su, gu) != 0)
                 return fail(SVI_ERR_HIP, "Cholesky kernels could not be configured (LDS request refused)");
             st = st1;
         }
         SVI_HIP(hipGetLastError());
     } else {
-        ba_schur(d, nullptr, s);
+        ba_schur(d, nullptr, ++ba->stage_seq, 0, 0, s);
         t.end(s);
         t.begin(SVI_PH_ASSEMBLE, s); assemble(ba); t.end(s);
         SVI_HIP(hipGetLastError());
         SVI_TRY(allreduce(ba, ba->lin_local ? d.red_base : d.g, (size_t)d.red_count + (ba->lin_local ? 2 : 0)));
         t.begin(SVI_PH_CHOLESKY, s);
-        if (d.NT > 0 && chol_factor_solve(ba->plan, d.S, d.Lt, d.Linv, d.g, d.dx, lambda, 6 * d.Pf, d.chol_status, s, tailp, &tail_done) != 0)
+        if (d.NT > 0 && chol_factor_range(ba->plan, d.S, d.Lt, d.Linv, d.g, d.dx, lambda, 6 * d.Pf, d.chol_status, s, tailp, &tail_done, 0, ba->plan.n_steps, 1, Su, gu) != 0)
             return fail(SVI_ERR_HIP, "Cholesky kernels could not be configured (LDS request refused)");
         t.end(s);
     }
@@ -1209,9 +1233,10 @@ int svi_ba_debug_reduced_system(svi_ba* ba, double lambda, double* S, double* g,
     ba->spec_lin_state = -1; // (a block that ended on a rejected speculated trial leaves the buffers of ANOTHER state's sweep behind)
     SVI_TRY(linearize(ba));
     SVI_HIP(hipMemsetAsync(d.chol_status, 0, sizeof(int), ba->stream));
+    set_assembly_flags(ba);
     SVI_TRY(zero_reduced_system(ba));
     ba_invert_landmarks(d, lambda, ba->stream);
-    ba_schur(d, nullptr, ba->stream);
+    ba_schur(d, nullptr, ++ba->stage_seq, 0, 0, ba->stream);
     assemble(ba);
     SVI_HIP(hipGetLastError());
     SVI_TRY(allreduce(ba, d.g, (size_t)d.red_count));

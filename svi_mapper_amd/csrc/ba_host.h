@@ -73,6 +73,9 @@ struct svi_ba {
     unsigned long long* sig_lin = nullptr;                 // main -> Schur stream: the linearisation (and H_ll^-1) of this trial is ready
     unsigned long long* sig_stage[svi::kMaxStages] = {};   // Schur stream -> main: stage s of this trial is reduced
     unsigned long long stage_seq = 0;                      // sequence number of the last staged trial
+    bool upd_clean[2] = {true, true};                      // d.upd[q] is all zero (or will be when the next trial's factorisation reads it)
+    uint64_t staged_trials = 0;                            // staged trials so far: trial t uses d.upd[t & 1]
+    int schur_launch_wgs = 0, schur_reserve_per_se = 0;    // staged k_schur: workgroups launched (two per CU), CUs per shader engine it leaves empty
     bool overlap_ok = false;                               // the device supports stream waits on memory and the streams / signals exist
     std::vector<int> sub_stage_ptr, level_stage;           // host mirrors of the stage ranges (sub-tiles, dependency levels)
     int spec_lin_state = -1;   // state whose Jacobian sweep + pose-only edges are already enqueued (speculation on "accepted"), or -1
@@ -80,7 +83,7 @@ struct svi_ba {
     bool host_stale = false; // an optimize() has run since the host copy of the estimates was refreshed (ensure_host)
     bool lin_local = false; // several ranks: the last linearisation kept its pose sums local (see linearize())
     bool initialized = false;
-    svi::BaDev d{};
+    svi::BaDev d{}, d_copy{};   // d_copy: what was sent to BaDev::self
     svi::CholPlan plan{};
     int cur = 0;
     std::vector<svi::DevBuf> pool;  // the device buffers of initialize(), in allocation order; kept (and grown) across calls

@@ -908,7 +908,106 @@ __device__ __forceinline__ void slab_store(double* p, double v, bool through)
     else *p = v;
 }
 
-__global__ __launch_bounds__(kBlock) void k_schur(BaDev d, int stage0, int stage1, StageSignals sg)
+// agent-scope load (bypasses the CU's L1): data another workgroup of the SAME launch has stored write-through
+__device__ __forceinline__ double ld_agent(const double* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// One cell (24 x 24 entries: 4 x 4 poses) of a stored sub-tile, by ONE wave: pose terms minus the slabs of the cell's quarter jobs
+// in list order (a fixed order: the result does not depend on which wave gets here), identity padding, and - for a diagonal cell -
+// its 24 rows of g.  Called by the wave whose slab was the last of the cell to arrive (or, for a cell without slabs, by the wave
+// the cell is dealt to); the slabs of the other waves were stored write-through and are read past the L1.
+// A function of its own (inlined into k_schur it costs that kernel its second wave per SIMD: 256 VGPRs).  It reads the layout from
+// the copy of BaDev that lives in device memory (d.self): the kernel's own argument handed over by reference would be copied to
+// scratch memory and every argument of the kernel indexed there.  The three switches the host sets per trial travel as `flags`.
+__device__ __noinline__ void assemble_cell(const BaDev* __restrict__ dp, int flags, int cell, int lane, bool through)
+{
+    const BaDev& d = *dp;
+    const bool add_pose_terms = (flags & 1) != 0, add_aux_blocks = (flags & 2) != 0;
+    constexpr int NE = 9; // 36 x 16 values of the cell's slabs / 64 lanes
+    const int sub = cell >> 2, u = (cell >> 1) & 1, vv = cell & 1;
+    const int cx = d.sub_cx[sub], cy = d.sub_cy[sub], n = 6 * d.Pf, TS = d.TS;
+    const int x0 = d.cell_qj_ptr[cell], x1 = d.cell_qj_ptr[cell + 1];
+    double v[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) v[k] = 0.0;
+    // the list is walked eight slabs at a time (72 loads in flight per lane: a slab that another XCD stored write-through comes
+    // from memory, ~2 us away - one slab after the other the hot diagonal cells, forty pieces, cost the whole kernel 100 us),
+    // subtracted in list order
+#ifndef SCHUR_ASM_NB
+#define SCHUR_ASM_NB 2
+#endif
+    constexpr int NB = SCHUR_ASM_NB;
+    for (int x = x0; x < x1; x += NB) {
+        double w[NB][NE];
+#pragma unroll
+        for (int t = 0; t < NB; ++t) {
+            const int qa = d.cell_qj[min(x + t, x1 - 1)];
+            const double* sa = d.slab + (size_t)(qa >> 2) * 36 * 64 + (qa & 3) * 16;
+#pragma unroll
+            for (int k = 0; k < NE; ++k) { const int e = lane + 64 * k; w[t][k] = ld_agent(sa + (e >> 4) * 64 + (e & 15)); }
+        }
+#pragma unroll
+        for (int t = 0; t < NB; ++t)
+            if (x + t < x1) {
+#pragma unroll
+                for (int k = 0; k < NE; ++k) v[k] -= w[t][k];
+            }
+    }
+    const bool diag_cell = cx == cy && u == vv;
+    const int R0 = cx * 48, C0 = cy * 48;
+    double* out = d.S + (size_t)d.sub_tile[sub] * TS * TS + (size_t)(R0 % TS) * TS + (C0 % TS);
+    const int a0 = add_aux_blocks ? d.sub_aux_ptr[sub] : 0, a1 = add_aux_blocks ? d.sub_aux_ptr[sub + 1] : 0;
+    // pose terms of the diagonal blocks (requested together, in front of the odometry blocks' index chains)
+    double hp[NE];
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int e = lane + 64 * k, q = e >> 4, l16 = e & 15, bi = l16 >> 2, bj = l16 & 3, rr = q / 6, cc = q % 6;
+        const int r = cx * 8 + 4 * u + bi;
+        const int a = rr < cc ? rr : cc, b = rr < cc ? cc : rr;
+        hp[k] = (add_pose_terms && diag_cell && bi == bj && r < d.Pf) ? d.Hpp[(size_t)21 * r + (a * 6 - a * (a - 1) / 2) + (b - a)] : 0.0;
+    }
+    for (int x = a0; x < a1; ++x) { // odometry blocks of this sub-tile (a handful): each one lands on the lanes that hold its block
+        const int ref = d.sub_aux_ref[x], ke = ref >> 1, tr = ref & 1;
+        const int ri = d.pose_red[d.se3_i[ke]], rj = d.pose_red[d.se3_j[ke]];
+        const int rhi = tr ? rj : ri, rlo = tr ? ri : rj;
+        const int l16 = lane & 15;
+        if ((rhi % 8) != 4 * u + (l16 >> 2) || (rlo % 8) != 4 * vv + (l16 & 3)) continue; // (the block of a lane is the same for all its nine values)
+#pragma unroll
+        for (int k = 0; k < NE; ++k) {
+            const int q = (lane + 64 * k) >> 4, rr = q / 6, cc = q % 6;
+            hp[k] += tr ? d.se3_out[(size_t)120 * ke + 72 + 6 * cc + rr] : d.se3_out[(size_t)120 * ke + 72 + 6 * rr + cc];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < NE; ++k) {
+        const int e = lane + 64 * k, q = e >> 4, l16 = e & 15, bi = l16 >> 2, bj = l16 & 3, rr = q / 6, cc = q % 6;
+        const int r = (4 * u + bi) * 6 + rr, c = (4 * vv + bj) * 6 + cc;
+        double val = v[k] + hp[k];
+        if (R0 + r >= n || C0 + c >= n) val = (R0 + r == C0 + c) ? 1.0 : 0.0; // identity padding
+        slab_store(out + (size_t)r * TS + c, val, through);
+    }
+    if (diag_cell && lane < 24) { // right-hand side of the cell's four poses
+        const int bi = lane / 6, comp = lane % 6, row = R0 + (4 * u + bi) * 6 + comp;
+        double g = 0.0;
+        if (row < n) {
+            if (add_pose_terms) g = d.bp[row];
+            for (int x = x0; x < x1; x += 16) {
+                double g4[16];
+#pragma unroll
+                for (int t = 0; t < 16; ++t) g4[t] = ld_agent(d.gslab + ((size_t)d.cell_qj[min(x + t, x1 - 1)] * 6 + comp) * 4 + bi);
+#pragma unroll
+                for (int t = 0; t < 16; ++t) if (x + t < x1) g -= g4[t];
+            }
+        }
+        slab_store(d.g + row, g, through);
+    }
+}
+
+// reserve_per_se > 0 (staged launches beside a running factorisation): workgroups that land on compute units 2 .. 2 + reserve_per_se - 1
+// of a shader engine leave at once - those CUs stay EMPTY for the factorisation's workgroups (which fit neither beside two Schur
+// workgroups nor, by registers, beside one) and its pivot chain shares no SIMD with a Schur wave.  The jobs are therefore not tied to
+// block indices in a staged launch: a workgroup draws the next group of sixteen quarter jobs of ITS XCD (HW_REG_XCC_ID, not
+// blockIdx % 8) from a ticket counter per stage and XCD until none is left.
+__global__ __launch_bounds__(kBlock) void k_schur(BaDev d, int stage0, int stage1, StageSignals sg, int reserve_per_se)
 {
     // The operands of kSchurBatch passes are staged in a wave-private LDS region, double buffered: the
     // global loads of batch k+1 are in flight while batch k is being multiplied out of LDS.
@@ -921,9 +1020,38 @@ __global__ __launch_bounds__(kBlock) void k_schur(BaDev d, int stage0, int stage
     const int qt = lane >> 4, i = (lane >> 2) & 3, j = lane & 3;
     const int4* __restrict__ items = reinterpret_cast<const int4*>(d.it_pack);
     const unsigned below_i = (1u << i) - 1u, below_j = (1u << j) - 1u;
-    const bool through = stage1 - stage0 > 1;
+    const bool through = stage1 - stage0 > 1 || d.asm_in_schur != 0;
+    const bool asm_here = d.asm_in_schur == 1; // (2: ablation - write-through slabs, but the k_assemble launch sums them)
+    // several ranks, pose sums not exchanged on their own: this rank's chi2 of the linearisation rides in front of g
+    // (rewritten per trial: the all-reduce leaves the total there)
+    if (asm_here && d.lin_from_red && blockIdx.x == 0 && threadIdx.x == 0) { d.red_base[0] = d.lin_scal[0]; d.red_base[1] = d.lin_scal[1]; }
+    const bool ticketed = stage1 - stage0 > 1;
+    int xcc = (int)blockIdx.x & 7;
+    if (ticketed) {
+        unsigned hw = 0, xc = 0;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xc));
+        xcc = (int)(xc & 7u);
+        const int cu = (int)((hw >> 8) & 0xFu);
+        if (reserve_per_se > 0 && cu >= 2 && cu < 2 + reserve_per_se) return; // (the whole workgroup: it lives on one CU)
+    }
+    const int groups = d.n_jobs / 32; // groups of sixteen quarter jobs per XCD and stage
+    int* const tickets = d.ticket + (size_t)(sg.seq & 1ull) * kMaxStages * 8;
+    __shared__ int s_grp;
     for (int stage = stage0; stage < stage1; ++stage) {
-    const int job = stage * d.n_jobs + blockIdx.x * (kBlock / 64) + wave;
+    for (int round = 0;; ++round) {
+    int grp = (int)blockIdx.x >> 3;
+    if (ticketed) {
+        __syncthreads(); // (the readers of the last ticket are done with it)
+        if (threadIdx.x == 0) s_grp = __hip_atomic_fetch_add(tickets + stage * 8 + xcc, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();
+        grp = s_grp;
+        if (grp >= groups) break;
+    } else if (round > 0) break;
+    const int slot = (8 * grp + xcc) * (kBlock / 64) + wave; // job inside the stage
+    const int job = stage * d.n_jobs + slot;
+    int mycell = -1;   // (lanes 0, 16, 32, 48) the cell this quarter's slab belongs to; last: its arrival completed the cell
+    bool last = false;
     const int it0 = d.qj_begin[4 * job + qt], it1 = d.qj_end[4 * job + qt];
     const bool diag = d.qj_diag[4 * job + qt] != 0;
     const int n_pass = d.job_len[job];
@@ -1045,19 +1173,51 @@ __global__ __launch_bounds__(kBlock) void k_schur(BaDev d, int stage0, int stage
 #pragma unroll
         for (int q = 0; q < 6; ++q) slab_store(d.gslab + ((size_t)(4 * job + qt) * 6 + q) * 4 + i, gacc[q], through);
     }
+    if (asm_here) {
+        // The slabs of this wave have left for memory; each of its (up to four) pieces is counted at its cell, and where the count
+        // is complete this wave sums the cell: no k_assemble launch, no kernel boundary between reduction and factorisation.
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if ((lane & 15) == 0) {
+            mycell = d.qj_cell[4 * job + qt];
+            if (mycell >= 0) {
+                const int np = d.cell_qj_ptr[mycell + 1] - d.cell_qj_ptr[mycell];
+                const int k = __hip_atomic_fetch_add(d.cell_count + mycell, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                last = k == np - 1;
+                if (last) __hip_atomic_store(d.cell_count + mycell, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+        }
     }
-    if (through) {
-        // every store of this wave has left for memory before the wave is counted; the last arrival of a stage (the counter goes
-        // back to zero for the next launch) tells whoever waits on the stage's value
+    }
+    if (asm_here) {
+        // cells to sum: those this wave's slabs completed, then its share of the stage's cells that no slab reaches (dealt round
+        // the waves) - one loop, so that assemble_cell is inlined once
+        unsigned long long todo = __ballot(last);
+        int o = d.orphan_ptr[stage] + slot;
+        const int o1 = d.orphan_ptr[stage + 1];
+        for (;;) {
+            int cell;
+            if (todo) { const int src = __ffsll((long long)todo) - 1; todo &= todo - 1; cell = __shfl(mycell, src); }
+            else if (o < o1) { cell = d.orphan_cell[o]; o += d.n_jobs; }
+            else break;
+            assemble_cell(d.self, (d.add_pose_terms ? 1 : 0) | (d.add_aux_blocks ? 2 : 0), cell, lane, through);
+        }
+    }
+    if (ticketed) {
+        // every store of this wave has left for memory before its job is counted; the last job of a stage (the counter goes back
+        // to zero for the next launch, and so do the OTHER parity's tickets of this stage, which the next launch draws from) tells
+        // whoever waits on the stage's value
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         if (lane == 0) {
-            const int total = (int)gridDim.x * (kBlock / 64);
             const int k = __hip_atomic_fetch_add(d.stage_count + stage, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (k == total - 1) {
+            if (k == d.n_jobs - 1) {
                 __hip_atomic_store(d.stage_count + stage, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                int* const other = d.ticket + (size_t)((sg.seq & 1ull) ^ 1ull) * kMaxStages * 8 + stage * 8;
+#pragma unroll
+                for (int x = 0; x < 8; ++x) __hip_atomic_store(other + x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 if (sg.sig[stage]) __hip_atomic_store(sg.sig[stage], sg.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
             }
         }
+    }
     }
     }
 }
@@ -1581,10 +1741,14 @@ void ba_invert_landmarks(const BaDev& d, double lambda, void* st)
     if (d.Ll > 0) hipLaunchKernelGGL(k_invert_landmarks, dim3((d.Ll + kBlock - 1) / kBlock), dim3(kBlock), 0, S_(st), d, lambda);
 }
 // all stages in one launch; sg (optional): the values a waiting stream is released by, stage by stage
-void ba_schur(const BaDev& d, const StageSignals* sg, void* st)
+// seq: the trial's number among the staged launches of the handle (its parity picks the ticket set); reserve_per_se: see k_schur
+void ba_schur(const BaDev& d, const StageSignals* sg, unsigned long long seq, int reserve_per_se, int launch_wgs, void* st)
 {
-    StageSignals none{};
-    if (d.n_jobs > 0) hipLaunchKernelGGL(k_schur, dim3((d.n_jobs + 3) / 4), dim3(kBlock), 0, S_(st), d, 0, d.n_stages, sg ? *sg : none);
+    StageSignals s{};
+    if (sg) s = *sg;
+    s.seq = seq;
+    const int wgs = d.n_stages > 1 && launch_wgs > 0 ? launch_wgs : (d.n_jobs + 3) / 4;
+    if (d.n_jobs > 0) hipLaunchKernelGGL(k_schur, dim3(wgs), dim3(kBlock), 0, S_(st), d, 0, d.n_stages, s, reserve_per_se);
 }
 // sub-tiles [sub0, sub1)
 void ba_assemble(const BaDev& d, int sub0, int sub1, int accumulate, void* st)

@@ -98,7 +98,8 @@ struct Build {
     double chol_flops = 0.0;
     // Schur
     int n_sub = 0, n_items = 0, n_jobs = 0; // n_jobs: wavefront jobs PER STAGE (the kernel's grid), n_stages of them back to back
-    int n_stages = 1, schur_wgs = 0;
+    int n_stages = 1, schur_wgs = 0, schur_reserve_per_se = 0;
+    std::vector<int> qj_cell, orphan_ptr, orphan_cell; // cell of every quarter-job slot (-1: empty); per stage the cells no slab reaches
     std::vector<int> level_stage, sub_stage_ptr; // stage of every dependency level; sub-tiles [sub_stage_ptr[s], sub_stage_ptr[s+1]) belong to stage s
     int64_t total_pairs = 0;
     std::vector<int> sub_cx, sub_cy, sub_tile, it_pack, qj_begin, qj_end, qj_diag, job_len, job_merged, cell_qj_ptr, cell_qj, sub_aux_ptr, sub_aux_ref;
@@ -119,8 +120,8 @@ struct Build {
         pre_col.clear(); h_tgt_ptr.clear(); tgt_tile.clear(); tgt_row.clear(); tgt_pair_ptr.clear(); pair_a.clear();
         pair_b.clear(); pair_src.clear(); h_trsm_ptr.clear(); st_tile.clear(); st_col.clear(); sub_cx.clear(); sub_cy.clear();
         sub_tile.clear(); it_pack.clear(); qj_begin.clear(); qj_end.clear(); qj_diag.clear(); job_len.clear(); job_merged.clear();
-        cell_qj_ptr.clear(); cell_qj.clear(); sub_aux_ptr.clear(); sub_aux_ref.clear(); level_stage.clear(); sub_stage_ptr.clear();
-        n_stages = 1; schur_wgs = 0;
+        cell_qj_ptr.clear(); cell_qj.clear(); sub_aux_ptr.clear(); sub_aux_ref.clear(); level_stage.clear(); sub_stage_ptr.clear(); qj_cell.clear(); orphan_ptr.clear(); orphan_cell.clear();
+        n_stages = 1; schur_wgs = 0; schur_reserve_per_se = 0;
         Pn = Pf = Ltot = 0; Etot = 0; use_cpl = false; span = 0; L0 = Ll = E = Epm = 0; n_lm_blocks = n_chunks = 0; planes = 3;
         TS = 96; PB = 16; n = NT = n_tiles = n_tiles_orig = n_steps = 0; chol_flops = 0.0; n_sub = n_items = n_jobs = 0; total_pairs = 0;
     }
@@ -842,12 +843,16 @@ int schur_work_lists(Build& b)
     int n_cu = 256;
     if (const int cu = device_compute_units(ba->opt.device)) n_cu = cu;
     constexpr int NX = 8;
+    // `reserve` CUs per shader engine (32 of them: n_cu / 8 CUs each) are kept EMPTY by the staged launch (k_schur: workgroups that
+    // land there leave at once), so the launch is planned for two workgroups on each of the others (SVI_SCHUR_RESERVE_PER_SE)
     int reserve = 0;
     if (b.n_stages > 1) {
-        reserve = n_cu / 4;
-        if (const char* e = getenv("SVI_SCHUR_RESERVE_CUS")) reserve = std::min(std::max(atoi(e), 0), n_cu);
+        reserve = 1;
+        if (const char* e = getenv("SVI_SCHUR_RESERVE_PER_SE")) reserve = std::min(std::max(atoi(e), 0), 4);
     }
-    const int wg_cap = std::max(NX, ((2 * n_cu - reserve) / NX) * NX); // workgroups of the launch (a multiple of the XCD count)
+    b.schur_reserve_per_se = reserve;
+    const int n_se = std::max(n_cu / 8, 1);
+    const int wg_cap = std::max(NX, ((2 * (n_cu - reserve * n_se)) / NX) * NX); // workgroups with work (a multiple of the XCD count)
     b.schur_wgs = wg_cap;
     const int64_t qj_cap = (int64_t)16 * wg_cap;
     // XCD-aware placement.  Workgroups b and b + 8 share an XCD (its 4 MiB L2); an edge's operands are wanted by every cell of
@@ -937,7 +942,7 @@ int schur_work_lists(Build& b)
     if (b.dbg) {
         int nm = 0, nonempty = 0;
         for (size_t job = 0; job < n_jobs_all; ++job) { nm += b.job_merged[job]; nonempty += b.job_len[job] > 0; }
-        fprintf(stderr, "schur: %d stages x %d jobs (%d with work), %d of them single-cell (merged slabs), %d workgroups (%d CUs keep room)\n", b.n_stages, b.n_jobs,
+        fprintf(stderr, "schur: %d stages x %d jobs (%d with work), %d of them single-cell (merged slabs), %d workgroups (%d CUs per shader engine kept empty)\n", b.n_stages, b.n_jobs,
                 nonempty, nm, b.n_jobs / 4, reserve);
         for (int stage = 0; stage < b.n_stages; ++stage)
             fprintf(stderr, "  stage %d: sub-tiles %d, items %d, quarter jobs %d, piece length %d\n", stage, b.sub_stage_ptr[stage + 1] - b.sub_stage_ptr[stage],
@@ -957,6 +962,19 @@ int schur_work_lists(Build& b)
         b.cell_qj_ptr[n_cells] = (int)b.cell_qj.size();
         b.cell_qj.push_back(0); // (k_assemble requests a clamped index for cells without jobs: the list is never empty)
     }
+    // in-kernel assembly (k_schur): the wave whose slab is the LAST of a cell to arrive sums the cell's slabs into the tile; it finds
+    // the cell of its quarter jobs here.  Cells no slab ever reaches (fill-in tiles, the unused upper cell of a diagonal sub-tile,
+    // poses without landmarks) are written by the waves of their stage up front, from this list.
+    b.qj_cell.assign(slot_cell.begin(), slot_cell.end());
+    for (size_t k = 0; k < b.qj_cell.size(); ++k)
+        if (b.qj_cell[k] >= 0 && b.job_merged[k >> 2] && (k & 3) != 0) b.qj_cell[k] = -1; // (a merged wave arrives once, for its first quarter)
+    b.orphan_ptr.assign((size_t)b.n_stages + 1, 0);
+    for (int stage = 0; stage < b.n_stages; ++stage) {
+        b.orphan_ptr[stage] = (int)b.orphan_cell.size();
+        for (int c = 4 * b.sub_stage_ptr[stage]; c < 4 * b.sub_stage_ptr[stage + 1]; ++c)
+            if (b.cell_qj_ptr[c + 1] == b.cell_qj_ptr[c]) b.orphan_cell.push_back(c);
+    }
+    b.orphan_ptr[b.n_stages] = (int)b.orphan_cell.size();
     std::vector<std::vector<int>> taux(b.n_sub);
     for (int k = 0; k < (int)b.se3_i.size(); ++k) {
         const int ri = b.pose_red[b.se3_i[k]], rj = b.pose_red[b.se3_j[k]];
@@ -1064,6 +1082,9 @@ int upload(Build& b)
     SVI_TRY(up.alloc(2 + (size_t)NT * TS + (size_t)n_tiles * TS * TS, &d.red_base)); // two doubles in front: see linearize()
     d.g = d.red_base + 2;
     d.S = d.g + (size_t)NT * TS;
+    d.upd[0] = d.upd[1] = nullptr;
+    if (b.n_stages > 1) for (int q = 0; q < 2; ++q) SVI_TRY(up.alloc((size_t)NT * TS + (size_t)n_tiles * TS * TS, &d.upd[q])); // (zeroed)
+    ba->upd_clean[0] = ba->upd_clean[1] = true;
     SVI_TRY(up.alloc((size_t)n_tiles * TS * TS, &d.Lt));
     SVI_TRY(up.alloc((size_t)NT * TS * TS, &d.Linv));
     SVI_TRY(up.alloc((size_t)NT * TS, &d.dx));
@@ -1079,6 +1100,13 @@ int upload(Build& b)
     SVI_TRY(up.alloc((size_t)std::max(n_jobs, 1) * b.n_stages * 36 * 64, &d.slab, false));
     SVI_TRY(up.alloc((size_t)std::max(n_jobs, 1) * b.n_stages * 4 * 6 * 4, &d.gslab, false));
     SVI_TRY(up.alloc((size_t)b.n_stages + 1, &d.stage_count));
+    SVI_TRY(up.alloc((size_t)4 * std::max(n_sub, 1), &d.cell_count));
+    SVI_TRY(up.alloc((size_t)2 * kMaxStages * 8, &d.ticket));
+    ba->schur_launch_wgs = 2 * std::max(device_compute_units(ba->opt.device), 8);
+    ba->schur_reserve_per_se = b.schur_reserve_per_se;
+    SVI_TRY(up.up(b.qj_cell, &d.qj_cell));
+    SVI_TRY(up.up(b.orphan_ptr, &d.orphan_ptr));
+    SVI_TRY(up.up(b.orphan_cell, &d.orphan_cell));
     ba->sub_stage_ptr = b.sub_stage_ptr;
     ba->level_stage = b.level_stage;
     SVI_TRY(up.up(b.cell_qj_ptr, &d.cell_qj_ptr));
@@ -1089,6 +1117,12 @@ int upload(Build& b)
     SVI_TRY(up.up(b.sub_aux_ptr, &d.sub_aux_ptr));
     SVI_TRY(up.up(b.sub_aux_ref, &d.sub_aux_ref));
     d.add_pose_terms = d.add_aux_blocks = (o.rank == 0) ? 1 : 0;
+    // Staged reduction: the tiles are assembled inside k_schur, cell by cell, by whichever wave delivers a cell's last slab - a stage
+    // that is reported complete IS assembled, and the factorisation starts on it without a launch in between (SVI_ASM_KERNEL=1: by
+    // k_assemble launches on the factorisation's stream, adding to zeroed tiles).  One stage: the k_assemble launch (summing the
+    // cells at the end of the one Schur launch, where every wave finishes together, measured 17 us of tail against 15 us of launch).
+    d.asm_in_schur = (b.n_stages > 1 && getenv("SVI_ASM_KERNEL") == nullptr) ? 1 : 0;
+    if (const char* e = getenv("SVI_ASM_IN_SCHUR")) d.asm_in_schur = atoi(e); // (ablation)
     d.lin_from_red = 0;
     SVI_TRY(up.alloc(16, &d.scal));
     d.aux_blocks = std::max(1, (std::max(d.n_se3, d.n_accel) + 63) / 64);
@@ -1196,6 +1230,13 @@ int upload(Build& b)
         if (!ba->h_status) SVI_HIP(hipHostMalloc(reinterpret_cast<void**>(&ba->h_status), sizeof(int) * 4));
         ba->h_status[0] = ba->h_status[1] = 0;
         ba->pub_seq = 0;
+        {   // the finished structure once more, in device memory (BaDev::self)
+            BaDev* self = nullptr;
+            SVI_TRY(up.alloc((size_t)1, &self, false));
+            d.self = self;
+            ba->d_copy = d;   // (the source of the copy must outlive the asynchronous transfer)
+            SVI_HIP(hipMemcpyAsync(self, &ba->d_copy, sizeof(BaDev), hipMemcpyHostToDevice, ba->stream));
+        }
         ba_configure_kernels(TS);
         // the host vectors of this call are read by the copies above: drain before they go out of scope
         SVI_HIP(hipStreamSynchronize(ba->stream));

@@ -452,6 +452,36 @@ def test_long_trajectory_takes_the_per_level_backward_substitution(svi, oracle):
     assert abs(g.last_plain_chi2 - o.last_plain_chi2) <= 1e-6 * o.last_plain_chi2
 
 
+@pytest.mark.parametrize("overlap", [True, False])
+def test_staged_reduction_equals_single_launch(svi, oracle, overlap, monkeypatch):
+    """The staged Schur reduction (work lists cut by the dependency level of a tile's column, tiles summed
+    inside k_schur by the wave that delivers a cell's last slab, the factorisation reading S + S_upd and - with `overlap` - running
+    level by level on the main stream behind stream waits on memory values while k_schur is still reducing the later stages on a
+    second stream) is off by default; switched on, it must reproduce the single-launch path: same LM iterations, same estimates to
+    round-off, and the oracle's within the north_star tolerance."""
+    prob = synth.make_ba_problem(160, 12000, 90000, seed=0x51A6)
+    ref, _ = _make(svi.BundleAdjuster, prob)
+    ref.initialize()
+    assert ref.stats().chol_steps >= 5
+    done_ref = [ref.optimize(n) for n in (1, 4)]
+    Tr, pr = ref.get_poses()[1], ref.get_landmarks()[1]
+    monkeypatch.setenv("SVI_SCHUR_STAGES", "1,2,4")
+    if not overlap:
+        monkeypatch.setenv("SVI_NO_OVERLAP", "1")
+    g, _ = _make(svi.BundleAdjuster, prob)
+    g.initialize()
+    monkeypatch.delenv("SVI_SCHUR_STAGES")
+    done = [g.optimize(n) for n in (1, 4)]
+    assert done == done_ref and g.stats().chol_failures == 0
+    Tg, pg = g.get_poses()[1], g.get_landmarks()[1]
+    assert _rel(Tg, Tr) < 1e-9 and _rel(pg, pr) < 1e-9
+    assert abs(g.last_plain_chi2 - ref.last_plain_chi2) <= 1e-9 * ref.last_plain_chi2
+    o, _ = _make(oracle.OracleBA, prob)
+    o.initialize()
+    assert [o.optimize(n) for n in (1, 4)] == done
+    assert _rel(Tg[:, 9:], o.get_poses()[1][:, 9:]) < REL and _rel(pg, o.get_landmarks()[1]) < REL
+
+
 def test_fixed_and_closure_edges(svi, oracle, small):
     """Landmark-closure EdgePointXYZ with a fixed partner (Cg2oOptimizer.cpp:445-458) and a fixed landmark."""
     def build(cls):

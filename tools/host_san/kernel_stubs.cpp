@@ -11,7 +11,7 @@ void ba_pose_finalize(const BaDev&, const int*, int, int, int, double, void*) {}
 void ba_publish(const BaDev&, int, double*, int*, int, void*) {}
 void ba_lin_post(const BaDev&, int, void*) {}
 void ba_invert_landmarks(const BaDev&, double, void*) {}
-void ba_schur(const BaDev&, const StageSignals*, void*) {}
+void ba_schur(const BaDev&, const StageSignals*, unsigned long long, int, int, void*) {}
 void ba_assemble(const BaDev&, int, int, int, void*) {}
 void ba_update_poses(const BaDev&, int, double, int, int, void*) {}
 void ba_backsub_chi2(const BaDev&, int, double, void*) {}
@@ -23,5 +23,5 @@ void ba_gather_edges(const double*, const uint8_t*, const int*, const int*, int,
 void ba_configure_kernels(int) {}
 int chol_potrf_probe(int, int, int, double*) { return 0; }
 int chol_factor_solve(const CholPlan&, double*, double*, double*, double*, double*, double, int, int*, void*, const PoseTail*, int* done) { if (done) *done = 0; return 0; }
-int chol_factor_range(const CholPlan&, double*, double*, double*, double*, double*, double, int, int*, void*, const PoseTail*, int* done, int, int, int) { if (done) *done = 0; return 0; }
+int chol_factor_range(const CholPlan&, double*, double*, double*, double*, double*, double, int, int*, void*, const PoseTail*, int* done, int, int, int, double*, double*) { if (done) *done = 0; return 0; }
 } // namespace svi
