@@ -22,7 +22,10 @@ enum : int { kTypeXYZ = 0, kTypeDepth = 1, kTypeDisparity = 2 };
 enum : unsigned { kFlagTypeMask = 3u, kFlagRobust = 4u };
 
 constexpr int kLmBlockEdges = 256;   // lm-major kernels: one workgroup owns whole landmarks, <= 256 edges
-constexpr int kPoseChunk    = 1024;  // pose-major kernel: one workgroup sums <= 1024 edges of one pose
+#ifndef SVI_POSE_CHUNK
+#define SVI_POSE_CHUNK 1024
+#endif
+constexpr int kPoseChunk    = SVI_POSE_CHUNK;  // pose-major kernel: one workgroup sums <= 1024 edges of one pose
 constexpr int kMaxTile      = 96;
 constexpr int kMaxStages    = 8;     // stages of the Schur reduction
 
