@@ -471,6 +471,7 @@ def main():
                     help="N > 1: strong = the literal config 4 (500 key frames / 100 k landmarks / 800 k edges) split N ways - the "
                          "headline (auto); weak = N x config-4 landmarks over the same key frames, value = N x iterations/s. The "
                          "other one is measured too and reported beside the headline (other_scaling)")
+    ap.add_argument("--no-other-scaling", action="store_true", help="N > 1: measure the headline scaling mode only")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-matcher", action="store_true")
     ap.add_argument("--no-frontend", action="store_true")
@@ -503,7 +504,8 @@ def main():
     if world > 1:
         # rank 0 generates (and caches) the synthetic graphs, the others pick the cache up afterwards
         if rank == 0:
-            cached_problem(world)
+            if not (args.no_other_scaling and args.scaling == "strong"):
+                cached_problem(world)
             cached_problem(1)
         dist.barrier()
 
@@ -574,7 +576,7 @@ def main():
     dt, stored = head["dt"], head["stored"]
     units = world if args.scaling == "weak" else 1     # weak: shard-iterations per second over the whole job
     other = None
-    if world > 1:
+    if world > 1 and not args.no_other_scaling:
         mode = "strong" if args.scaling == "weak" else "weak"
         o = measure(cached_problem(scale_of[mode]), args.steps, args.warmup)
         ou = world if mode == "weak" else 1
