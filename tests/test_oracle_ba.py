@@ -255,3 +255,80 @@ def test_converged_minimum_matches_scipy(oracle):
         assert np.abs(To[k, :9].reshape(3, 3) - Rs[k]).max() < 1e-5 and np.abs(To[k, 9:] - ts[k]).max() < 1e-5
     n_obs = np.bincount([e[2] for e in edges], minlength=n_lm)
     assert np.abs(po - P)[n_obs >= 3].max() < 1e-4 and np.abs(po - P).max() < 5e-3   # (one or two inverse-depth sightings: a flat valley)
+
+
+def test_measurement_rules_against_a_vectorised_reading(oracle):
+    """("oracle and product are textual twins" for the edge construction rule.)  A third statement of
+    Cg2oOptimizer::_setLandmarkMeasurementsWORLD (Cg2oOptimizer.cpp:1383-1466) and the three factories (:999-1073), written from
+    the reference as whole-array numpy over ALL measurements at once - no per-measurement loop, no else-if ladder: masks.
+    The oracle's stored edges (kind, vertices, measurement, information) must be exactly these, in insertion order."""
+    prob = synth.make_ba_problem(14, 900, 7000, seed=97)
+    cam = prob["cam"]
+    o = oracle.OracleBA(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"])
+    stored = synth.build_ba_graph(o, prob)
+    ty, pid, lid, z, info = o.get_edges()
+    # -- the reference, restated on arrays --------------------------------------------------------------------------------
+    k, l = prob["obs_kf"], prob["obs_lm"]
+    R, t = prob["R_init"][k], prob["t_init"][k]                 # vertex estimates at insertion time: nothing has been optimised yet
+    p_est = np.einsum("nji,nj->ni", R, prob["lm_init"][l] - t)  # estimate().inverse() * landmark               (:1402)
+    xyz = prob["xyz"]
+    l2_abs = (xyz * xyz).sum(1)                                 # vecPointXYZLEFT.squaredNorm()                 (:1405)
+    l2_rel = (p_est * p_est).sum(1) / l2_abs                    #                                               (:1406)
+    consistent = (0.75 < l2_rel) & (1.25 > l2_rel)              #                                               (:1409)
+    w = 1.0 / xyz[:, 2]                                         # dInformationFactor                            (:1412)
+    is_xyz = consistent & (10.0 > l2_abs)                       # m_dMaximumReliableDepthForPointXYZL2, Cg2oOptimizer.h:92
+    is_dep = consistent & ~is_xyz & (50.0 > l2_abs)             # ...ForUVDepthL2, :93
+    disp = (prob["uvL"][:, 0] - prob["uvR"][:, 0]).astype(np.float64)   # cv::Point2f difference: float arithmetic     (:1440)
+    is_dsp = consistent & ~is_xyz & ~is_dep & (10000.0 > l2_abs) & (1.0 < disp)   # ...ForUVDisparityL2, :94; "at least 2 pixels" (:1443)
+    keep = is_xyz | is_dep | is_dsp
+    kind = np.where(is_xyz, 0, np.where(is_dep, 1, 2))
+    uvl = prob["uvL"].astype(np.float64)
+    z_ref = np.where(is_xyz[:, None], xyz,
+                     np.where(is_dep[:, None], np.column_stack([uvl, xyz[:, 2]]),
+                              np.column_stack([uvl, disp / (cam["fx"] * cam["baseline_m"])])))          # (:1010, :1032, :1058-1061)
+    third = np.where(is_xyz, 1000.0, np.where(is_dep, 100.0, 1000.0))                                   # (:1014, :1038, :1066)
+    first = np.where(is_xyz, 1000.0, 1.0)
+    info_ref = np.zeros((len(w), 6))
+    info_ref[:, 0] = info_ref[:, 3] = w * first
+    info_ref[:, 5] = w * third
+    # -- compare ----------------------------------------------------------------------------------------------------------
+    assert keep.sum() == len(ty) and list(stored) == [int(is_xyz.sum()), int(is_dep.sum()), int(is_dsp.sum())]
+    assert min(stored) > 20 and (~keep).sum() > 20, "all three kinds and some rejected measurements are wanted"
+    np.testing.assert_array_equal(ty, kind[keep])
+    np.testing.assert_array_equal(pid, synth.POSE_ID_SHIFT + k[keep])
+    np.testing.assert_array_equal(lid, l[keep])
+    np.testing.assert_array_equal(z, z_ref[keep])
+    np.testing.assert_array_equal(info, info_ref[keep])
+
+
+def test_keyframe_edges_against_a_vectorised_reading(oracle):
+    """The pose chain of Cg2oOptimizer::_setAndgetPose (Cg2oOptimizer.cpp:1229-1290), again from the reference on whole arrays with
+    4x4 homogeneous matrices (the oracle and the product work on R | t pairs): EdgeSE3 measurement = X_from^-1 X_cur (:1257),
+    information = 100000 I (m_matInformationPose, :72) with the translation block scaled by 1 / (1 + |t_Z|^2) (:1260-1264);
+    one unit-information gravity edge per key frame (:982-997), the first pose fixed without an odometry edge (:41-54)."""
+    prob = synth.make_ba_problem(9, 60, 300, seed=5)
+    cam = prob["cam"]
+    o = oracle.OracleBA(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"])
+    synth.build_ba_graph(o, prob)
+    ty, ia, ib, z, info = o.get_aux()
+    n = prob["n_kf"]
+    X = np.tile(np.eye(4), (n, 1, 1))
+    X[:, :3, :3] = prob["R_init"]
+    X[:, :3, 3] = prob["t_init"]
+    Z = np.linalg.inv(X[:-1]) @ X[1:]                               # (:1257)
+    f = 1.0 / (1.0 + (Z[:, :3, 3] ** 2).sum(1))                     # (:1260)
+    se3 = np.flatnonzero(ty == ty[np.flatnonzero(ib >= 0)[0]])      # the kind that connects two poses
+    acc = np.flatnonzero(ib < 0)
+    assert len(se3) == n - 1 and len(acc) == n
+    np.testing.assert_array_equal(ia[se3], synth.POSE_ID_SHIFT + np.arange(n - 1))
+    np.testing.assert_array_equal(ib[se3], synth.POSE_ID_SHIFT + np.arange(1, n))
+    np.testing.assert_allclose(z[se3, :9].reshape(-1, 3, 3), Z[:, :3, :3], rtol=0, atol=1e-14)
+    np.testing.assert_allclose(z[se3, 9:], Z[:, :3, 3], rtol=0, atol=1e-12)
+    full = np.zeros((n - 1, 6, 6))
+    iu = np.triu_indices(6)
+    full[:, iu[0], iu[1]] = info[se3]                               # upper triangle, row-major
+    want = np.tile(100000.0 * np.eye(6), (n - 1, 1, 1))
+    want[:, :3, :3] *= f[:, None, None]
+    np.testing.assert_allclose(full, want, rtol=1e-14, atol=0)
+    np.testing.assert_array_equal(np.sort(ia[acc]), synth.POSE_ID_SHIFT + np.arange(n))
+    np.testing.assert_array_equal(info[acc, :6], np.tile([1.0, 0, 0, 1, 0, 1], (n, 1)))
