@@ -47,29 +47,58 @@ __device__ void quat_R(double w, double x, double y, double z, double* R)
     R[6] = txz - twy;       R[7] = tyz + twx;       R[8] = 1 - (txx + tyy);
 }
 
-// Eigen::LDLT: lower Cholesky with diagonal pivoting; x holds the right-hand side, then the solution
-__device__ void ldlt_solve6(double* A, double* x, int* perm)
+// Eigen::LDLT: lower Cholesky with diagonal pivoting; x holds the right-hand side, then the solution.
+// Everything lives in REGISTERS: all loops are unrolled and the one dynamic index - the pivot row p - is resolved by predicated
+// swaps over the candidates, so no element is ever addressed through LDS (the version that kept the 6x6 system in LDS paid an LDS
+// round trip for each of its ~300 dependent accesses: ~8 of the 15 us of an iteration).  Operation order as before: same bits.
+__device__ __forceinline__ void ldlt_solve6(double (&A)[36], double (&x)[6])
 {
+    int perm[6];
+#pragma unroll
     for (int k = 0; k < 6; ++k) {
         int p = k;
         double big = fabs(A[7 * k]);
+#pragma unroll
         for (int i = k + 1; i < 6; ++i) if (fabs(A[7 * i]) > big) { big = fabs(A[7 * i]); p = i; }
         perm[k] = p;
-        if (p != k) {
-            for (int j = 0; j < 6; ++j) { const double t = A[6 * k + j]; A[6 * k + j] = A[6 * p + j]; A[6 * p + j] = t; }
-            for (int j = 0; j < 6; ++j) { const double t = A[6 * j + k]; A[6 * j + k] = A[6 * j + p]; A[6 * j + p] = t; }
-        }
-        const double d = A[7 * k];
-        if (d == 0.0) continue;
-        for (int i = k + 1; i < 6; ++i) A[6 * i + k] /= d;
+#pragma unroll
         for (int i = k + 1; i < 6; ++i)
-            for (int j = k + 1; j <= i; ++j) { A[6 * i + j] -= A[6 * i + k] * d * A[6 * j + k]; A[6 * j + i] = A[6 * i + j]; }
+            if (p == i) { // swap rows, then columns, k <-> i (static indices under a uniform predicate)
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { const double t = A[6 * k + j]; A[6 * k + j] = A[6 * i + j]; A[6 * i + j] = t; }
+#pragma unroll
+                for (int j = 0; j < 6; ++j) { const double t = A[6 * j + k]; A[6 * j + k] = A[6 * j + i]; A[6 * j + i] = t; }
+            }
+        const double d = A[7 * k];
+        if (d != 0.0) {
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i) A[6 * i + k] /= d;
+#pragma unroll
+            for (int i = k + 1; i < 6; ++i)
+#pragma unroll
+                for (int j = k + 1; j <= i; ++j) { A[6 * i + j] -= A[6 * i + k] * d * A[6 * j + k]; A[6 * j + i] = A[6 * i + j]; }
+        }
     }
-    for (int k = 0; k < 6; ++k) if (perm[k] != k) { const double t = x[k]; x[k] = x[perm[k]]; x[perm[k]] = t; }
-    for (int i = 0; i < 6; ++i) for (int j = 0; j < i; ++j) x[i] -= A[6 * i + j] * x[j];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) if (perm[k] == i) { const double t = x[k]; x[k] = x[i]; x[i] = t; }
+    }
+#pragma unroll
+    for (int i = 0; i < 6; ++i)
+#pragma unroll
+        for (int j = 0; j < i; ++j) x[i] -= A[6 * i + j] * x[j];
+#pragma unroll
     for (int i = 0; i < 6; ++i) x[i] = (A[7 * i] == 0.0) ? 0.0 : x[i] / A[7 * i];
-    for (int i = 5; i >= 0; --i) for (int j = i + 1; j < 6; ++j) x[i] -= A[6 * j + i] * x[j];
-    for (int k = 5; k >= 0; --k) if (perm[k] != k) { const double t = x[k]; x[k] = x[perm[k]]; x[perm[k]] = t; }
+#pragma unroll
+    for (int i = 5; i >= 0; --i)
+#pragma unroll
+        for (int j = i + 1; j < 6; ++j) x[i] -= A[6 * j + i] * x[j];
+#pragma unroll
+    for (int k = 5; k >= 0; --k) {
+#pragma unroll
+        for (int i = k + 1; i < 6; ++i) if (perm[k] == i) { const double t = x[k]; x[k] = x[i]; x[i] = t; }
+    }
 }
 
 __device__ void inverse_t(const double* T, double* ti)
@@ -81,8 +110,6 @@ __global__ __launch_bounds__(kThreads) void k_stereo_posit(PositArgs a)
 {
     __shared__ double s_T[12];
     __shared__ double s_red[kThreads / 64][kAcc];
-    __shared__ double s_H[36], s_dx[6];   // the 6x6 system of thread 0 (dynamic indexing: LDS, not scratch)
-    __shared__ int    s_perm[6];
     __shared__ int    s_m, s_stop;
     __shared__ double s_prev;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -172,16 +199,21 @@ __global__ __launch_bounds__(kThreads) void k_stereo_posit(PositArgs a)
         }
         __syncthreads();
         if (tid == 0) {
-            double* H = s_H;
-            double* dx = s_dx;
-            double* sum = s_red[0]; // wave sums folded into row 0 in ascending wave order
+            double H[36], dx[6], sum[kAcc]; // wave sums added in ascending wave order; the 6x6 system in registers
+#pragma unroll
             for (int k = 0; k < kAcc; ++k) { double v = s_red[0][k]; for (int w = 1; w < kThreads / 64; ++w) v += s_red[w][k]; sum[k] = v; }
-            int q = 0;
-            for (int r = 0; r < 6; ++r) for (int c = r; c < 6; ++c) { H[6 * r + c] = sum[q]; H[6 * c + r] = sum[q]; ++q; }
+            {
+                int q = 0;
+#pragma unroll
+                for (int r = 0; r < 6; ++r)
+#pragma unroll
+                    for (int c = r; c < 6; ++c) { H[6 * r + c] = sum[q]; H[6 * c + r] = sum[q]; ++q; }
+            }
+#pragma unroll
             for (int k = 0; k < 6; ++k) dx[k] = -sum[21 + k];
             const double total = sum[27];
             const int inliers = static_cast<int>(sum[28]);
-            ldlt_solve6(H, dx, s_perm);                                                           // :109
+            ldlt_solve6(H, dx);                                                                   // :109
             double dR[9] = {1, 0, 0, 0, 1, 0, 0, 0, 1};
             const double w2 = dx[3] * dx[3] + dx[4] * dx[4] + dx[5] * dx[5];
             if (1.0 > w2) quat_R(sqrt(1.0 - w2), dx[3], dx[4], dx[5], dR);
