@@ -1,5 +1,5 @@
 """N > 1 path on CPU: the landmark partition and the one exchange step (sum of the reduced camera
-normal equations), exercised with torch.distributed / gloo at world_size 2. The arithmetic on each
+normal equations), exercised with torch.distributed / gloo at world_size 2 and 8. The arithmetic on each
 rank is the CPU oracle (this is a test); the product's sharded path runs in tests/test_dist_gpu.py."""
 import os
 import socket
@@ -86,7 +86,10 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_two_rank_gloo_sum_equals_unsharded():
+@pytest.mark.parametrize("world", [2, 8])
+def test_gloo_sum_equals_unsharded(world):
+    """world 8 = the split of the target machine (one shard per GPU of a node); several of the eight shards of this small graph
+    hold a handful of landmarks only"""
     import torch.multiprocessing as mp
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -94,11 +97,11 @@ def test_two_rank_gloo_sum_equals_unsharded():
     s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     for p in procs:
-        p.join(120)
+        p.join(240)
         assert p.exitcode == 0
     eS, eg = q.get(timeout=10)
     assert eS < 1e-12 and eg < 1e-12
