@@ -167,10 +167,22 @@ class OnlineTracker:
         self.kf_in_graph = 0
         self.T_last_kf = None
         self.stats = dict(frames=0, stage1=0, stage2=0, stage3=0, posit_fail=0, ba_calls=0, ba_iterations=0, landmarks_created=0, ba_ms=0.0,
-                          ba_initialize_ms=0.0)
+                          ba_initialize_ms=0.0, detector_ms=0.0, detector_calls=0, library_ms=0.0)
+
+    def _lib(self, fn, *a, **k):
+        """a call into the library (through its ctypes shim), host wall clock accumulated in stats['library_ms'] - without what the
+        detector stand-in spends inside it (the cascades call back into Python for stage 2's key points)"""
+        import time
+        d0, t0 = self.stats["detector_ms"], time.perf_counter()
+        try:
+            return fn(*a, **k)
+        finally:
+            self.stats["library_ms"] += 1e3 * (time.perf_counter() - t0) - (self.stats["detector_ms"] - d0)
 
     # the stand-in for GFTT inside the stage-2 rectangles: the pixels where the live landmarks' texture points project
     def _detector(self, T_w2l_true):
+        import time
+        t_in = time.perf_counter()
         R = torch.tensor(T_w2l_true[:9].reshape(3, 3), device=self.dev)
         tt = torch.tensor(T_w2l_true[9:], device=self.dev)
         n = self.n_used
@@ -182,7 +194,19 @@ class OnlineTracker:
         uR = torch.round(F * (pc[:, 0] - BASE) / z + CX)
         pts = {"left": torch.stack([uL, v], 1)[ok].float(), "right": torch.stack([uR, v], 1)[ok].float()}
 
+        self.stats["detector_ms"] += 1e3 * (time.perf_counter() - t_in)
+
         def detect(side, rect):
+            # (host wall clock of the stand-in, accumulated: the caller's detector - OpenCV's GFTT in the reference - is not part of
+            # the hot path; torch.nonzero below makes the host wait for the device, that wait is inside the figure)
+            t0 = time.perf_counter()
+            try:
+                return detect_(side, rect)
+            finally:
+                self.stats["detector_ms"] += 1e3 * (time.perf_counter() - t0)
+                self.stats["detector_calls"] += 1
+
+        def detect_(side, rect):
             p = pts[side]
             ul = rect[:, :2].floor()
             lr = rect[:, 2:].floor()
@@ -228,7 +252,7 @@ class OnlineTracker:
             n = uv_d.shape[0]
             if kp_o.shape[0] != n:
                 return 0
-        res = self.fm.add_new_landmarks(self.brief, uv_d.float().contiguous(), kp, desc.contiguous())
+        res = self._lib(self.fm.add_new_landmarks, self.brief, uv_d.float().contiguous(), kp, desc.contiguous())
         ok = res.status == 0
         m = int(ok.sum())
         if m == 0:
@@ -332,8 +356,8 @@ class OnlineTracker:
     def step(self, t, images):
         """one frame of CTrackerSVI::_trackLandmarks"""
         dev = self.dev
-        self.brief.set_image("left", images[0])
-        self.brief.set_image("right", images[1])
+        self._lib(self.brief.set_image, "left", images[0])
+        self._lib(self.brief.set_image, "right", images[1])
         n = self.n_used
         # the motion prior of CTrackerSVI::process (:330-470): rotation increment from the gyroscope (here: the stream's true
         # relative rotation plus a little noise), translation increment carried over from the last frame pair
@@ -348,8 +372,8 @@ class OnlineTracker:
         dp_T = np.array(self.dp_T)
         args = (dp_T, 1.0, self.xyz[:n], self.kp_size[:n], self.last_disp[:n], self.uv_ref[:n], self.dp_index[:n])
         act = self.alive[:n].to(torch.uint8)
-        plan = self.fm.plan(T_est, *args)
-        r12, pose = self.fm.pose_stereo_posit(plan, det, self.brief, self.last_l[:n], self.last_r[:n], self.posit, self.T_w2l, np.zeros(3), T_est, act)
+        plan = self._lib(self.fm.plan, T_est, *args)
+        r12, pose = self._lib(self.fm.pose_stereo_posit, plan, det, self.brief, self.last_l[:n], self.last_r[:n], self.posit, self.T_w2l, np.zeros(3), T_est, act)
         if pose.status != 0:
             self.stats["posit_fail"] += 1
             T_now = T_est
@@ -357,9 +381,9 @@ class OnlineTracker:
             T_now = np.array(pose.T_world_to_left[:])
         ok12 = r12.status == 0
         # epipolar search with the refined pose for what the pose stage did not find
-        plan2 = self.fm.plan(T_now, *args)
-        r3 = self.fm.track_epipolar(plan2, self.brief, self.last_l[:n], self.ref_l[:n], (self.alive[:n] & ~ok12).to(torch.uint8), detector=det,
-                                    last_desc_right=self.last_r[:n])
+        plan2 = self._lib(self.fm.plan, T_now, *args)
+        r3 = self._lib(self.fm.track_epipolar, plan2, self.brief, self.last_l[:n], self.ref_l[:n], (self.alive[:n] & ~ok12).to(torch.uint8), detector=det,
+                       last_desc_right=self.last_r[:n])
         ok3 = r3.status == 0
         ok = ok12 | ok3
         uvl = torch.where(ok3[:, None], r3.uv_left, r12.uv_left)
@@ -416,7 +440,7 @@ class OnlineTracker:
         ur = torch.cat(self.m_uvr)[order].contiguous()
         PL = torch.tensor(np.array(self.frames_PL), device=self.dev)
         PR = torch.tensor(np.array(self.frames_PR), device=self.dev)
-        out, st, err, its = self.lmopt.optimize(PL, PR, seg, fr, ul, ur, self.xyz[:n].contiguous())
+        out, st, err, its = self._lib(self.lmopt.optimize, PL, PR, seg, fr, ul, ur, self.xyz[:n].contiguous())
         good = ((st == 1) | (st == 2)) & self.alive[:n] & ~self.in_graph[:n]
         self.xyz[:n] = torch.where(good[:, None], out, self.xyz[:n])
 
