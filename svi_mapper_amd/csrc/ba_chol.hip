@@ -20,6 +20,7 @@
 
 #include <atomic>
 #include <cstdint>
+#include <cstdlib>
 #include <vector>
 
 #include "ba_device.h"
@@ -164,6 +165,29 @@ __device__ __forceinline__ double fast_rsqrt(double x)
 
 constexpr int kPotrfThreads = 512;
 
+// row r of y = L^-1 g from an LDS image of L^-1 (row stride LD, zero above the diagonal): four partial sums over a quarter of the
+// columns each, four interleaved chains inside a quarter - term for term what the factorising workgroup computes when it finishes
+// y_k itself (k_potrf_inv), so that a consumer that forms y_q on the spot (StepArgs::defer_y) gets the same bits
+template <int TS, int LD>
+__device__ __forceinline__ double y_row(const double* sXinv, int r, const double* gv)
+{
+    constexpr int YC = TS / 4;
+    double p[4];
+#pragma unroll
+    for (int part = 0; part < 4; ++part) {
+        double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+#pragma unroll
+        for (int c = part * YC; c < part * YC + YC; c += 4) {
+            a0 = fma(sXinv[r * LD + c], gv[c], a0);
+            a1 = fma(sXinv[r * LD + c + 1], gv[c + 1], a1);
+            a2 = fma(sXinv[r * LD + c + 2], gv[c + 2], a2);
+            a3 = fma(sXinv[r * LD + c + 3], gv[c + 3], a3);
+        }
+        p[part] = (a0 + a1) + (a2 + a3);
+    }
+    return (p[0] + p[1]) + (p[2] + p[3]);
+}
+
 // "not computed yet" in the solution vector of the one-launch backward substitution: a NaN with a payload no computation produces
 __device__ __forceinline__ double solve_pending() { return __longlong_as_double(0x7FF8DEADBEEF0001LL); }
 __device__ __forceinline__ bool is_solve_pending(double v) { return __double_as_longlong(v) == 0x7FF8DEADBEEF0001LL; }
@@ -231,7 +255,7 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, co
                                                  double* __restrict__ y, double* __restrict__ Lt, const int* __restrict__ pre_tile_g,
                                                  const int* __restrict__ pre_col_g, int npre, double* s_g, const double* __restrict__ S_all,
                                                  const double* __restrict__ Linv_all, double* sT, const int* __restrict__ status,
-                                                 int it0, int it1, int ic0, int ic1, double gk, double* s_cf)
+                                                 int it0, int it1, int ic0, int ic1, double gk, double* s_cf, int defer_y, double* s_y)
 {
     // the status word goes first, the operand tiles right behind it: the test waits for its own load only
     const int failed_before = *status;
@@ -320,6 +344,9 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, co
                     block_to_global<TS>(lb, Lout, r0, c0);
                 }
             }
+            // y_q for the forward substitution below: as it came (s_rs), or - defer_y: s_rs holds the final g_q - formed here from the
+            // image of L_qq^-1, on the wave whose block of the product above is the cheapest
+            if (g_thr) s_y[gt] = defer_y ? y_row<TS, LD>(sL, gt, s_rs) : s_rs[gt];
             __syncthreads();
             TS_MARK(2); // L(k,q) formed
 #pragma unroll
@@ -329,10 +356,10 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, co
                 double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll 6
                 for (int m = 0; m < TS; m += 4) {
-                    a0 = fma(sT[gt * LD + m], s_rs[m], a0);
-                    a1 = fma(sT[gt * LD + m + 1], s_rs[m + 1], a1);
-                    a2 = fma(sT[gt * LD + m + 2], s_rs[m + 2], a2);
-                    a3 = fma(sT[gt * LD + m + 3], s_rs[m + 3], a3);
+                    a0 = fma(sT[gt * LD + m], s_y[m], a0);
+                    a1 = fma(sT[gt * LD + m + 1], s_y[m + 1], a1);
+                    a2 = fma(sT[gt * LD + m + 2], s_y[m + 2], a2);
+                    a3 = fma(sT[gt * LD + m + 3], s_y[m + 3], a3);
                 }
                 gk -= (a0 + a1) + (a2 + a3);
             }
@@ -367,7 +394,10 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, co
         __syncthreads();
     }
     }
-    if (g_thr) s_g[gt] = gk; // g_k minus the pending sources: read again when y_k is formed, many barriers from here
+    if (g_thr) {
+        s_g[gt] = gk; // g_k minus the pending sources: read again when y_k is formed, many barriers from here
+        if (defer_y) y[k * TS + gt] = gk; // (final: every earlier column has subtracted its part; the consumers form y_k from it)
+    }
 #pragma unroll
     for (int u = 0; u < PER; ++u)
 #pragma unroll
@@ -500,6 +530,10 @@ __device__ __forceinline__ int potrf_sweep_mfma(const double* __restrict__ A, co
 struct StepArgs {
     int n_chain;                 // workgroups 0..n_chain-1 factorise one column each, the rest run grouped updates
     int last_level;              // nothing is eliminated after these columns: they finish x_k themselves
+    int defer_y;                 // the forward vector y_k = L_kk^-1 g_k is NOT formed by the workgroup that factorises column k (1450 cycles at
+                                 // the very end of a level's critical path): it leaves the final g_k in the y buffer, and whoever needs y_k -
+                                 // the next level's pending updates, the grouped updates' g rows, the backward substitution - multiplies
+                                 // by L_kk^-1, which it has staged anyway
     const int* chain_col;        // [n_chain] tile columns of this level
     const int4* chain_desc;      // [n_chain] pairs of int4: {column, diagonal tile, first pre, #pre}, {first sub-diagonal tile, #, 0, 0}
     const int* diag_tile;        // [NT]
@@ -538,6 +572,7 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
     __shared__ __align__(16) double s_buf[kScratch];
     __shared__ double s_rs[TS];        // 1/sqrt(d_j) = 1/L_jj
     __shared__ double s_g[TS];
+    __shared__ double s_y[TS];         // y_q of the pending source being applied
     __shared__ __align__(16) double s_cf[(TS / 4) * 6]; // Lu^-1 of every quad (below the diagonal)
     static_assert(sizeof(double) * (2 * TS * LD + kScratch + 2 * TS) <= 160 * 1024, "potrf LDS budget (160 KiB per workgroup)");
     double (*s_col)[TS][4] = reinterpret_cast<double (*)[TS][4]>(s_buf);
@@ -581,7 +616,7 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
         if (gt >= 0 && gt < TS) { gk = g[k * TS + gt]; if constexpr (SPLIT) gk += gu[k * TS + gt]; }
     }
     const int rc = potrf_sweep_mfma<TS, SPLIT>(A, SPLIT ? Su + (size_t)tile_id * TS * TS : nullptr, Su, Lg, sL, sX, s_col, s_rs, k, n, lambda, stop_after, y, Lt, sa.pre_tile + pre0, sa.pre_col + pre0, npre, s_g, S,
-                                        Linv, sm + 2 * TS * LD, status, it0, it1, ic0, ic1, gk, s_cf);
+                                        Linv, sm + 2 * TS * LD, status, it0, it1, ic0, ic1, gk, s_cf, Fold<TS>::on ? sa.defer_y : 0, s_y);
     if (rc == 2) return;                                  // an earlier column of this trial had failed
     if (rc == 1) { if (tid == 0) *status = k + 1; return; } // not positive definite
     if (stop_after == 5 || (stop_after >= 6 && stop_after <= 9) || stop_after == 1) return;
@@ -707,6 +742,11 @@ __global__ __launch_bounds__(kPotrfThreads) void k_potrf_inv(double* __restrict_
         }
     }
     TS_MARK(9); // X stored
+    if (Fold<TS>::on && sa.defer_y && !sa.last_level) { // y_k is formed by its consumers; the backward substitution waits on the marker
+        if (tid < TS && xs != y) xs[k * TS + tid] = solve_pending();
+        TS_MARK(10);
+        return;
+    }
     // y_k = L_kk^-1 g_k (g_k is final: every earlier column has already subtracted its part).  Four threads per row, a quarter of
     // the columns each, the partial sums added in a fixed order: one thread per row was a chain of TS LDS reads and multiply-adds
     // (0.65 us) at the very end of the level.
@@ -805,6 +845,7 @@ __device__ void gemm_target_block(double* __restrict__ S, double* __restrict__ S
         double* sXq = sm + 2 * TS * LD;
         double* sLa = sm + 3 * TS * LD;
         double* sLb = sm + 4 * TS * LD;
+        __shared__ double s_yq[TS];
         const int t = work;
         const int p0 = sa.tgt_pair_ptr[t], p1 = sa.tgt_pair_ptr[t + 1];
         const int row = sa.tgt_row[t];
@@ -840,6 +881,7 @@ __device__ void gemm_target_block(double* __restrict__ S, double* __restrict__ S
                 block_to_lds<LD>(lb, which ? sLb : sLa, r0, c0);
                 if (same) block_to_global<TS>(lb, Lout, r0, c0); // the diagonal target of row i owns L(i,q)
             }
+            if (g_thread && sa.defer_y) s_yq[threadIdx.x - 64] = y_row<TS, LD>(sXq, threadIdx.x - 64, yq); // (yq points at the final g_q)
             __syncthreads();
             const double* pa = sLa;
             const double* pb = same ? sLa : sLb;
@@ -850,13 +892,14 @@ __device__ void gemm_target_block(double* __restrict__ S, double* __restrict__ S
             }
             if (g_thread) { // forward substitution rides along: g_i -= L_iq y_q
                 const int r = threadIdx.x - 64;
+                const double* yv = sa.defer_y ? s_yq : yq; // (defer_y: formed below the first barrier from the staged L_qq^-1)
                 double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
 #pragma unroll 6
                 for (int m = 0; m < TS; m += 4) {
-                    a0 = fma(sLa[r * LD + m], yq[m], a0);
-                    a1 = fma(sLa[r * LD + m + 1], yq[m + 1], a1);
-                    a2 = fma(sLa[r * LD + m + 2], yq[m + 2], a2);
-                    a3 = fma(sLa[r * LD + m + 3], yq[m + 3], a3);
+                    a0 = fma(sLa[r * LD + m], yv[m], a0);
+                    a1 = fma(sLa[r * LD + m + 1], yv[m + 1], a1);
+                    a2 = fma(sLa[r * LD + m + 2], yv[m + 2], a2);
+                    a3 = fma(sLa[r * LD + m + 3], yv[m + 3], a3);
                 }
                 gacc += (a0 + a1) + (a2 + a3);
             }
@@ -1194,7 +1237,7 @@ __device__ void pose_tail_wg(const PoseTail& pt, const double* x, int* status, i
 template <int TS>
 __global__ __launch_bounds__(kPotrfThreads) void k_back_solve_all(const SolveRec* __restrict__ recs, const double* __restrict__ Lt,
                                                                   const double* __restrict__ Linv, const double* __restrict__ y, double* x, int* status,
-                                                                  PoseTail pt, int kSpinLimit)
+                                                                  PoseTail pt, int kSpinLimit, int defer_y)
 {
     static_assert(TS == 48, "written for the 48-wide tile (one column set per lane)");
     if (pt.src != nullptr && blockIdx.x == gridDim.x - 1) { // the extra workgroup: the trial poses
@@ -1240,7 +1283,9 @@ __global__ __launch_bounds__(kPotrfThreads) void k_back_solve_all(const SolveRec
             for (int w = 0; w < RB; ++w) lv[s][w] = L[w * TS + c0];
         }
     }
-    const double yk = tid < TS ? y[k * TS + tid] : 0.0;
+    // (defer_y: the y buffer holds the final g_k, y_k = L_kk^-1 g_k is formed here - same sums as the factorisation would have taken)
+    double yk = 0.0;
+    if (tid < TS) yk = defer_y ? y_row<TS, TS>(Linv + (size_t)k * TS * TS, tid, y + k * TS) : y[k * TS + tid];
     double a0 = 0.0, a0b = 0.0;
     bool bad = false;
 #pragma unroll
@@ -1309,6 +1354,8 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
     // the solution vector carries "pending" markers until its entries are computed
     const bool one_launch = TS == 48 && p.solve_recs != nullptr && p.n_solve_cols > 0 && p.ybuf != nullptr;
     double* const yv = one_launch ? p.ybuf : x;
+    static const bool no_defer = getenv("SVI_NO_DEFER_Y") != nullptr; // (A/B)
+    const int defer_y = (one_launch && !no_defer) ? 1 : 0;
     constexpr int LD = Lds<TS>::LD, Q = TS / kOB;
     const size_t lds_p = sizeof(double) * (Fold<TS>::on ? 5 : 2) * (size_t)TS * LD; // folded: the grouped updates stage five images
     constexpr int kTB = TrsmBlock<TS>::TB, QT = TS / kTB;
@@ -1329,6 +1376,7 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
     for (int st = st_begin; st < st_end; ++st) {
         const int c0 = p.h_step_ptr[st], nc = p.h_step_ptr[st + 1] - c0;
         const int t0 = p.h_tgt_ptr[st], ntg = p.h_tgt_ptr[st + 1] - t0;
+        sa.defer_y = defer_y;
         sa.n_chain = nc; sa.last_level = st == p.n_steps - 1; sa.chain_col = p.step_col + c0; sa.chain_desc = reinterpret_cast<const int4*>(p.step_desc) + 2 * c0;
         sa.tgt_tile = p.tgt_tile + t0; sa.tgt_row = p.tgt_row + t0; sa.tgt_pair_ptr = p.tgt_pair_ptr + t0;
         if (p.h_chain_inl) sa.inl = p.h_chain_inl[st]; else sa.inl.n = 0;
@@ -1360,7 +1408,7 @@ int run(const CholPlan& p, double* S, double* Lt, double* Linv, double* g, doubl
             PoseTail pt{};
             if (tail) { pt = *tail; if (tail_done) *tail_done = 1; }
             hipLaunchKernelGGL(k_back_solve_all<TS>, dim3(p.n_solve_cols + (tail ? 1 : 0)), dim3(kPotrfThreads), 0, s, p.solve_recs, Lt, Linv, yv, x, status, pt,
-                               g_backsolve_spin_limit.load(std::memory_order_relaxed));
+                               g_backsolve_spin_limit.load(std::memory_order_relaxed), defer_y);
             return 0;
         }
     }
