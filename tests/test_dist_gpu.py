@@ -10,7 +10,7 @@ from svi_mapper_amd import synth
 pytestmark = pytest.mark.gpu
 
 
-def _run_sharded(svi, prob, n_ranks, iters, extra=None, make=None):
+def _run_sharded(svi, prob, n_ranks, iters, extra=None, make=None, until=False):
     """n_ranks handles in n_ranks threads of one process; the hook sums their buffers in a fixed order.
     make(rank, n_ranks) (optional) builds the handle with its graph instead of synth.build_ba_graph(prob)."""
     import torch
@@ -51,7 +51,10 @@ def _run_sharded(svi, prob, n_ranks, iters, extra=None, make=None):
             ba.set_allreduce(hook_for(rank))
             ba.initialize()
             done, lams = [], []
-            for n in iters:
+            if until:   # the whole _optimizeUnLimited schedule (every block's lambda_0 exchange included)
+                done = list(ba.optimize_until())
+                lams.append(ba.lm_lambda)
+            for n in ([] if until else iters):
                 done.append(ba.optimize(n))
                 lams.append(ba.lm_lambda)
             st = ba.stats()
@@ -139,6 +142,28 @@ def test_c4_eight_shards_equal_unsharded(svi):
         assert o[7] == out[0][7]                                  # the same damping on every rank, bit for bit
         assert np.array_equal(o[1], out[0][1])
         assert np.abs(o[1] - T).max() < 1e-9 and np.abs(o[2] - p).max() < 1e-9 * np.abs(p).max()
+        assert abs(o[3][0] - chi[0]) <= 1e-9 * chi[0]
+
+
+def test_c4_eight_shards_full_schedule(svi):
+    """BASELINE config 4 in eight landmark shards through the WHOLE _optimizeUnLimited schedule (61 LM iterations: seven
+    lambda_0 exchanges, sixty iterations whose pose sums stay local): the same nominal / executed counts as the unsharded
+    solve, the same estimates (the shards' partial sums are added in another order than the single handle's: 1e-8, not bits),
+    and bit-identical poses and damping between the eight ranks."""
+    prob = synth.make_c4()
+    cam = prob["cam"]
+    ref = svi.BundleAdjuster(cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["baseline_m"])
+    synth.build_ba_graph(ref, prob)
+    ref.initialize()
+    done = list(ref.optimize_until())
+    T, p, chi = ref.get_poses()[1], ref.get_landmarks()[1], ref.chi2()
+    ref.close()
+    assert done[1] >= 21
+    out = _run_sharded(svi, prob, 8, (), until=True)
+    for o in out:
+        assert o[0] == done and o[6] == 0
+        assert o[7] == out[0][7] and np.array_equal(o[1], out[0][1])
+        assert np.abs(o[1] - T).max() < 1e-8 * max(1.0, np.abs(T).max()) and np.abs(o[2] - p).max() < 1e-8 * np.abs(p).max()
         assert abs(o[3][0] - chi[0]) <= 1e-9 * chi[0]
 
 
